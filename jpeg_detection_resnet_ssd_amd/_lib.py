@@ -1,0 +1,78 @@
+"""ctypes binding of csrc/libdj_hip.so (the C ABI declared in include/dj_hip.h).
+
+There is no CPU fallback: if the library is missing the import of any compute entry point
+raises, and every call checks the return code and raises `DjError` with dj_last_error()."""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_long, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdj_hip.so")
+
+
+class DjError(RuntimeError):
+    pass
+
+
+class ConvDesc(Structure):
+    """Mirror of `dj_conv2d_desc` (include/dj_hip.h)."""
+    _fields_ = [(n, c_int) for n in (
+        "batch", "in_h", "in_w", "in_c", "out_h", "out_w", "out_c",
+        "kernel_h", "kernel_w", "stride_h", "stride_w", "dilation_h", "dilation_w",
+        "pad_top", "pad_left", "ld_x", "ld_y")]
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (idempotent).  Raises DjError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DjError(
+            "HIP extension %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the compute path)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    _declare(lib)
+    _lib = lib
+    return lib
+
+
+# name -> (restype, [argtypes]); kept in one table so the "exports every symbol" test can walk it
+FP = c_void_p  # device float* passed as integer address
+SIGNATURES = {
+    "dj_last_error": (c_char_p, []),
+    "dj_abi_version": (c_int, []),
+    "dj_conv2d_fwd_stats_rows": (c_int, [POINTER(ConvDesc)]),
+    "dj_conv2d_nhwc_fwd": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, FP, c_int, c_int, FP, c_void_p]),
+    "dj_conv2d_nhwc_dgrad": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, c_int, c_void_p]),
+    "dj_conv2d_nhwc_wgrad": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, c_int, c_void_p]),
+}
+
+
+def _declare(lib):
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+
+
+def check(rc, what=""):
+    if rc < 0:
+        msg = load().dj_last_error()
+        raise DjError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))
+    return rc
+
+
+def ptr(t):
+    """Device address of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

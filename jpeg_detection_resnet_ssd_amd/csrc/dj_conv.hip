@@ -1,0 +1,335 @@
+// Host launchers of the implicit-GEMM convolution (see dj_igemm.h for the kernel).
+#include "../../include/dj_hip.h"
+#include "dj_igemm.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+void dj_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* dj_last_error(void) { return g_err; }
+extern "C" int dj_abi_version(void) { return 1; }
+
+// ---------------------------------------------------------------------------------
+// tile configurations
+// ---------------------------------------------------------------------------------
+struct TileCfg {
+  int bm, bn;
+};
+static const TileCfg kCfgs[] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}};
+enum { CFG_128x128 = 0, CFG_128x64, CFG_64x64, CFG_128x32, N_CFG };
+
+template <int BM, int BN, int WM, int WN, int AM, int BMD>
+static int launch_one(const DjIgemmParams& p, int splits, hipStream_t s) {
+  using Cfg = DjIgemmCfg<BM, BN, WM, WN, AM, BMD>;
+  auto kern = dj_igemm_kernel<BM, BN, WM, WN, AM, BMD>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       Cfg::SMEM_BYTES);
+    if (e != hipSuccess) {
+      dj_set_error("hipFuncSetAttribute(%d B LDS): %s", Cfg::SMEM_BYTES, hipGetErrorString(e));
+      return DJ_ERR_HIP;
+    }
+    attr_done = true;
+  }
+  int tiles_m = dj_cdiv(p.M, BM), tiles_n = dj_cdiv(p.N, BN);
+  dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)splits);
+  hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::SMEM_BYTES, s, p);
+  DJ_CHECK_LAUNCH("dj_igemm_kernel");
+  return DJ_OK;
+}
+
+template <int AM, int BMD>
+static int launch_cfg(int cfg, const DjIgemmParams& p, int splits, hipStream_t s) {
+  switch (cfg) {
+    case CFG_128x128: return launch_one<128, 128, 2, 2, AM, BMD>(p, splits, s);
+    case CFG_128x64: return launch_one<128, 64, 2, 2, AM, BMD>(p, splits, s);
+    case CFG_64x64: return launch_one<64, 64, 2, 2, AM, BMD>(p, splits, s);
+    case CFG_128x32: return launch_one<128, 32, 4, 1, AM, BMD>(p, splits, s);
+  }
+  dj_set_error("bad tile cfg %d", cfg);
+  return DJ_ERR_ARG;
+}
+
+// Pick a tile shape: smallest padded-N waste first, then enough workgroups to fill
+// 256 CUs (2 resident workgroups each for the large tiles).
+static int choose_cfg(long M, long N, long K, bool allow_split, int* splits_out) {
+  int bn;
+  if (N > 96) {
+    // 128 vs 64: both pad N to the same multiple of 64 or better with 64
+    long pad128 = (long)dj_cdiv(N, 128) * 128, pad64 = (long)dj_cdiv(N, 64) * 64;
+    bn = (pad64 < pad128) ? 64 : 128;
+  } else if (N > 32 && (long)dj_cdiv(N, 64) * 64 <= (long)dj_cdiv(N, 32) * 32) {
+    bn = 64;
+  } else {
+    bn = 32;
+  }
+  int cfg;
+  auto tiles = [&](int bm, int b_n) { return (long)dj_cdiv(M, bm) * dj_cdiv(N, b_n); };
+  if (bn == 128) {
+    if (tiles(128, 128) >= 384)
+      cfg = CFG_128x128;
+    else if (tiles(128, 64) >= 256)
+      cfg = CFG_128x64;
+    else
+      cfg = CFG_64x64;
+  } else if (bn == 64) {
+    cfg = (tiles(128, 64) >= 384) ? CFG_128x64 : CFG_64x64;
+  } else {
+    cfg = CFG_128x32;
+  }
+  int splits = 1;
+  if (allow_split) {
+    long t = tiles(kCfgs[cfg].bm, kCfgs[cfg].bn);
+    if (t < 256) {
+      long want = (512 + t - 1) / t;
+      long maxs = K / 256;  // keep >= 8 K-steps per split
+      if (maxs < 1) maxs = 1;
+      splits = (int)(want < maxs ? want : maxs);
+      if (splits < 1) splits = 1;
+    }
+  }
+  *splits_out = splits;
+  return cfg;
+}
+
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+static int check_desc(const dj_conv2d_desc* d) {
+  DJ_CHECK_ARG(d != nullptr, "conv desc is null");
+  DJ_CHECK_ARG(d->batch > 0 && d->in_h > 0 && d->in_w > 0 && d->in_c > 0 && d->out_h > 0 && d->out_w > 0 &&
+                   d->out_c > 0,
+               "conv desc: non-positive dimension");
+  DJ_CHECK_ARG(d->kernel_h > 0 && d->kernel_w > 0 && d->stride_h > 0 && d->stride_w > 0 && d->dilation_h > 0 &&
+                   d->dilation_w > 0,
+               "conv desc: non-positive kernel/stride/dilation");
+  DJ_CHECK_ARG(d->pad_top >= 0 && d->pad_left >= 0, "conv desc: negative padding");
+  DJ_CHECK_ARG(d->ld_x >= d->in_c && d->ld_y >= d->out_c, "conv desc: ld_x/ld_y smaller than channel count");
+  // every output pixel must read inside [-pad, in + pad_after): guaranteed if the last tap start is valid
+  long last_h = (long)(d->out_h - 1) * d->stride_h - d->pad_top;
+  long last_w = (long)(d->out_w - 1) * d->stride_w - d->pad_left;
+  DJ_CHECK_ARG(last_h < d->in_h && last_w < d->in_w, "conv desc: output grid larger than the input allows");
+  DJ_CHECK_ARG((long)d->batch * d->in_h * d->in_w * (long)d->ld_x < (1L << 31) &&
+                   (long)d->batch * d->out_h * d->out_w * (long)d->ld_y < (1L << 31),
+               "conv desc: tensor exceeds 2^31 elements");
+  return DJ_OK;
+}
+
+__global__ void dj_relu_rows_kernel(float* y, long rows, int cols, int ld) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = rows * cols;
+  for (; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i / cols;
+    int c = (int)(i - r * cols);
+    float* p = y + r * ld + c;
+    *p = fmaxf(*p, 0.f);
+  }
+}
+
+static void fill_geom(DjIgemmParams& p, const dj_conv2d_desc* d) {
+  p.KH = d->kernel_h;
+  p.KW = d->kernel_w;
+  p.sH = d->stride_h;
+  p.sW = d->stride_w;
+  p.dH = d->dilation_h;
+  p.dW = d->dilation_w;
+  p.pT = d->pad_top;
+  p.pL = d->pad_left;
+}
+
+extern "C" int dj_conv2d_fwd_stats_rows(const dj_conv2d_desc* d) {
+  if (check_desc(d) != DJ_OK) return DJ_ERR_ARG;
+  int splits;
+  long M = (long)d->batch * d->out_h * d->out_w;
+  int cfg = choose_cfg(M, d->out_c, (long)d->kernel_h * d->kernel_w * d->in_c, false, &splits);
+  return dj_cdiv(M, kCfgs[cfg].bm);
+}
+
+extern "C" int dj_conv2d_nhwc_fwd(const dj_conv2d_desc* d, const float* x, const float* w, const float* bias,
+                                  float* y, const float* pro_scale, const float* pro_shift, int pro_relu, int relu,
+                                  float* stats, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  DJ_CHECK_ARG(x && w && y, "conv fwd: null tensor");
+  DJ_CHECK_ARG((pro_scale == nullptr) == (pro_shift == nullptr), "conv fwd: pro_scale/pro_shift must come together");
+  hipStream_t s = (hipStream_t)stream;
+  DjIgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = x;
+  p.B = w;
+  p.C = y;
+  p.bias = bias;
+  p.pro_scale = pro_scale;
+  p.pro_shift = pro_shift;
+  p.pro_relu = pro_relu;
+  p.stats = stats;
+  p.M = d->batch * d->out_h * d->out_w;
+  p.N = d->out_c;
+  p.K = d->kernel_h * d->kernel_w * d->in_c;
+  p.rowH = d->out_h;
+  p.rowW = d->out_w;
+  p.srcH = d->in_h;
+  p.srcW = d->in_w;
+  p.srcC = d->in_c;
+  p.ldsrc = d->ld_x;
+  fill_geom(p, d);
+  p.ldb = d->out_c;
+  p.ldc = d->ld_y;
+  p.cmap = 0;
+  p.relu = relu;
+  p.vecA = (d->in_c % 4 == 0) && (d->ld_x % 4 == 0) && aligned16(x) &&
+           (!pro_scale || (aligned16(pro_scale) && aligned16(pro_shift)));
+  p.vecB = (d->out_c % 4 == 0) && aligned16(w);
+  int splits = 1;
+  int cfg = choose_cfg(p.M, p.N, p.K, stats == nullptr, &splits);
+  p.kchunk = dj_cdiv(dj_cdiv(p.K, splits), DJ_BK) * DJ_BK;
+  splits = dj_cdiv(p.K, p.kchunk);
+  if (splits > 1) {
+    p.atomic = 1;
+    p.relu = 0;
+    hipError_t e = hipMemset2DAsync(y, (size_t)d->ld_y * 4, 0, (size_t)d->out_c * 4, (size_t)p.M, s);
+    if (e != hipSuccess) {
+      dj_set_error("conv fwd: memset: %s", hipGetErrorString(e));
+      return DJ_ERR_HIP;
+    }
+  }
+  if (int rc = launch_cfg<0, 0>(cfg, p, splits, s)) return rc;
+  if (splits > 1 && relu) {
+    long total = (long)p.M * p.N;
+    int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(dj_relu_rows_kernel, dim3(blocks), dim3(256), 0, s, y, (long)p.M, p.N, d->ld_y);
+    DJ_CHECK_LAUNCH("dj_relu_rows_kernel");
+  }
+  return DJ_OK;
+}
+
+extern "C" int dj_conv2d_nhwc_dgrad(const dj_conv2d_desc* d, const float* dy, const float* w, const float* bias,
+                                    float* dx, int beta, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  DJ_CHECK_ARG(dy && w && dx, "conv dgrad: null tensor");
+  hipStream_t s = (hipStream_t)stream;
+  DjIgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = dy;
+  p.B = w;
+  p.C = dx;
+  p.bias = bias;
+  p.N = d->in_c;
+  p.srcC = d->out_c;
+  p.ldsrc = d->ld_y;
+  p.ldb = d->out_c;
+  p.bTapStride = (long)d->in_c * d->out_c;
+  p.ldc = d->ld_x;
+  p.beta = beta;
+  p.vecA = (d->out_c % 4 == 0) && (d->ld_y % 4 == 0) && aligned16(dy);
+  p.vecB = (d->out_c % 4 == 0) && aligned16(w);
+  const long in_pixels = (long)d->batch * d->in_h * d->in_w;
+  bool strided_1x1 = d->kernel_h == 1 && d->kernel_w == 1 && d->pad_top == 0 && d->pad_left == 0 &&
+                     (d->stride_h > 1 || d->stride_w > 1) && d->stride_h == d->stride_w && bias == nullptr;
+  int splits = 1;
+  if (strided_1x1) {
+    // compact GEMM over the output grid, rows scattered to the strided input pixels
+    p.M = d->batch * d->out_h * d->out_w;
+    p.K = d->out_c;
+    p.rowH = d->out_h;
+    p.rowW = d->out_w;
+    p.srcH = d->out_h;
+    p.srcW = d->out_w;
+    p.KH = p.KW = 1;
+    p.sH = p.sW = p.dH = p.dW = 1;
+    p.pT = p.pL = 0;
+    p.cmap = 1;
+    p.cgH = d->out_h;
+    p.cgW = d->out_w;
+    p.cH = d->in_h;
+    p.cW = d->in_w;
+    p.cS = d->stride_h;
+    if (!beta) {
+      hipError_t e = hipMemset2DAsync(dx, (size_t)d->ld_x * 4, 0, (size_t)d->in_c * 4, (size_t)in_pixels, s);
+      if (e != hipSuccess) {
+        dj_set_error("conv dgrad: memset: %s", hipGetErrorString(e));
+        return DJ_ERR_HIP;
+      }
+    }
+    int cfg = choose_cfg(p.M, p.N, p.K, false, &splits);
+    p.kchunk = dj_cdiv(p.K, DJ_BK) * DJ_BK;
+    return launch_cfg<0, 1>(cfg, p, 1, s);
+  }
+  p.M = (int)in_pixels;
+  p.K = d->kernel_h * d->kernel_w * d->out_c;
+  p.rowH = d->in_h;
+  p.rowW = d->in_w;
+  p.srcH = d->out_h;
+  p.srcW = d->out_w;
+  fill_geom(p, d);
+  p.cmap = 0;
+  int cfg = choose_cfg(p.M, p.N, p.K, true, &splits);
+  p.kchunk = dj_cdiv(dj_cdiv(p.K, splits), DJ_BK) * DJ_BK;
+  splits = dj_cdiv(p.K, p.kchunk);
+  if (splits > 1) {
+    p.atomic = 1;
+    if (!beta) {
+      hipError_t e = hipMemset2DAsync(dx, (size_t)d->ld_x * 4, 0, (size_t)d->in_c * 4, (size_t)in_pixels, s);
+      if (e != hipSuccess) {
+        dj_set_error("conv dgrad: memset: %s", hipGetErrorString(e));
+        return DJ_ERR_HIP;
+      }
+    }
+    p.beta = 0;
+  }
+  return launch_cfg<1, 1>(cfg, p, splits, s);
+}
+
+extern "C" int dj_conv2d_nhwc_wgrad(const dj_conv2d_desc* d, const float* x, const float* dy, float* dw,
+                                    const float* pro_scale, const float* pro_shift, int pro_relu, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  DJ_CHECK_ARG(x && dy && dw, "conv wgrad: null tensor");
+  DJ_CHECK_ARG((pro_scale == nullptr) == (pro_shift == nullptr), "conv wgrad: pro_scale/pro_shift must come together");
+  hipStream_t s = (hipStream_t)stream;
+  DjIgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = x;
+  p.B = dy;
+  p.C = dw;
+  p.pro_scale = pro_scale;
+  p.pro_shift = pro_shift;
+  p.pro_relu = pro_relu;
+  p.M = d->kernel_h * d->kernel_w * d->in_c;
+  p.N = d->out_c;
+  p.K = d->batch * d->out_h * d->out_w;
+  p.rowH = d->out_h;
+  p.rowW = d->out_w;
+  p.srcH = d->in_h;
+  p.srcW = d->in_w;
+  p.srcC = d->in_c;
+  p.ldsrc = d->ld_x;
+  fill_geom(p, d);
+  p.ldb = d->ld_y;
+  p.ldc = d->out_c;
+  p.cmap = 0;
+  p.vecA = (d->in_c % 4 == 0) && (d->ld_x % 4 == 0) && aligned16(x) &&
+           (!pro_scale || (aligned16(pro_scale) && aligned16(pro_shift)));
+  p.vecB = (d->out_c % 4 == 0) && (d->ld_y % 4 == 0) && aligned16(dy);
+  int splits = 1;
+  int cfg = choose_cfg(p.M, p.N, p.K, false, &splits);
+  long t = (long)dj_cdiv(p.M, kCfgs[cfg].bm) * dj_cdiv(p.N, kCfgs[cfg].bn);
+  long want = (768 + t - 1) / t;
+  long maxs = p.K / 128;
+  if (maxs < 1) maxs = 1;
+  splits = (int)(want < maxs ? want : maxs);
+  if (splits < 1) splits = 1;
+  p.kchunk = dj_cdiv(dj_cdiv(p.K, splits), DJ_BK) * DJ_BK;
+  splits = dj_cdiv(p.K, p.kchunk);
+  if (splits > 1) {
+    p.atomic = 1;
+    hipError_t e = hipMemsetAsync(dw, 0, (size_t)p.M * p.N * 4, s);
+    if (e != hipSuccess) {
+      dj_set_error("conv wgrad: memset: %s", hipGetErrorString(e));
+      return DJ_ERR_HIP;
+    }
+  }
+  return launch_cfg<2, 0>(cfg, p, splits, s);
+}

@@ -1,0 +1,512 @@
+// Implicit-GEMM convolution core for gfx950 (MI355X): exact-fp32 MFMA
+// (v_mfma_f32_32x32x2_f32), NHWC activations x HWIO weights, LDS-staged tiles.
+//
+// One templated kernel covers the three directions of keras.layers.Conv2D as the
+// reference uses it (localisation_part/models/keras_ssd300_dct_j2d_resnet.py:77-96,
+// 128-160, 483-545, 562-675) plus Conv2DTranspose (:1709-1711):
+//
+//   A-mode 0 (forward gather)  rows m = (img, oh, ow), k = (kh, kw, ci)
+//                              A[m][k] = src[img, oh*s + kh*d - pad, ow*s + kw*d - pad, ci]
+//   A-mode 1 (dgrad gather)    rows m = (img, ih, iw), k = (kh, kw, co)
+//                              A[m][k] = src[img, (ih + pad - kh*d)/s, (iw + pad - kw*d)/s, co]
+//   A-mode 2 (wgrad gather)    rows m' = (kh, kw, ci), k' = (img, oh, ow)   (A stored m-contiguous)
+//                              A[m'][k'] = src[img, oh*s + kh*d - pad, ow*s + kw*d - pad, ci]
+//   B-mode 0 (KN)              B[k][n] = Bp[k*ldb + n]                    (HWIO weights; dy rows)
+//   B-mode 1 (NK, per tap)     B[k=(tap,c)][n] = Bp[tap*bTapStride + n*ldb + c]   (HWIO read as W^T)
+//
+// The k order inside one 8-wide MFMA group is permuted identically for A and B
+// (lane half h takes k = 8*kk + 4*h + e), which lets k-contiguous operands be read
+// from LDS with one ds_read_b128 per 4 MFMAs.
+#pragma once
+#include "dj_common.h"
+
+#define DJ_BK 32
+
+struct DjIgemmParams {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;       // [N] or null; added in the epilogue
+  const float* pro_scale;  // [srcC] or null: A element -> A*scale[c] + shift[c] (in-bounds only)
+  const float* pro_shift;
+  float* stats;            // [tiles_m][2][N] column sum / sum-of-squares of the raw accumulator, or null
+  int M, N, K;
+  int kchunk;              // K range handled per blockIdx.y (multiple of DJ_BK)
+  // gather geometry
+  int rowH, rowW;          // pixel grid indexed by m (A-mode 0/1) or by k' (A-mode 2)
+  int srcH, srcW, srcC;    // gathered tensor
+  int ldsrc;               // floats between consecutive pixels of the gathered tensor
+  int KH, KW, sH, sW, dH, dW, pT, pL;
+  int ldb;
+  long bTapStride;
+  // epilogue
+  int ldc;                 // floats between consecutive C rows
+  int cmap;                // 0: row m -> m*ldc ; 1: m=(img,h,w) on (cgH,cgW) -> ((img*cH + h*cS)*cW + w*cS)*ldc
+  int cgH, cgW, cH, cW, cS;
+  int pro_relu;            // prologue ReLU after the affine
+  int relu;                // epilogue ReLU
+  int beta;                // 1: C = acc + C
+  int atomic;              // 1: atomicAdd into C (split-K)
+  int vecA, vecB;          // 16-byte loads legal for A / B
+};
+
+template <int BM, int BN, int WM, int WN, int AM, int BMD>
+struct DjIgemmCfg {
+  static constexpr int TM = BM / (32 * WM);
+  static constexpr int TN = BN / (32 * WN);
+  static constexpr int NA = BM / 32;  // float4 loads per thread per K-step for A
+  static constexpr int NB = BN / 32;
+  static constexpr bool A_KC = (AM != 2);
+  static constexpr bool B_KC = (BMD == 1);
+  static constexpr int LDA_S = A_KC ? (DJ_BK + 4) : BM;
+  static constexpr int A_ROWS = A_KC ? BM : DJ_BK;
+  static constexpr int LDB_S = B_KC ? (DJ_BK + 4) : BN;
+  static constexpr int B_ROWS = B_KC ? BN : DJ_BK;
+  static constexpr int A_FLOATS = A_ROWS * LDA_S;
+  static constexpr int B_FLOATS = B_ROWS * LDB_S;
+  static constexpr int STAGE_FLOATS = A_FLOATS + B_FLOATS;
+  static constexpr int SMEM_BYTES = 2 * STAGE_FLOATS * 4;
+};
+
+__device__ __forceinline__ f32x4 dj_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// Scalar fall-back of one gathered A element for A-modes 0/1 (used when 16-byte
+// loads are not legal, e.g. Cin = 3).
+template <int AM>
+__device__ __forceinline__ float dj_gather_elem(const DjIgemmParams& p, int pixbase, int rh, int rw, int k) {
+  if (k >= p.K) return 0.f;
+  int tap = k / p.srcC;
+  int c = k - tap * p.srcC;
+  int kh = tap / p.KW;
+  int kw = tap - kh * p.KW;
+  int h, w;
+  bool ok;
+  if (AM == 0) {
+    h = rh + kh * p.dH;
+    w = rw + kw * p.dW;
+    ok = (unsigned)h < (unsigned)p.srcH && (unsigned)w < (unsigned)p.srcW;
+  } else {
+    int th = rh - kh * p.dH, tw = rw - kw * p.dW;
+    ok = th >= 0 && tw >= 0;
+    h = th / p.sH;
+    w = tw / p.sW;
+    ok = ok && (h * p.sH == th) && (w * p.sW == tw) && h < p.srcH && w < p.srcW;
+  }
+  if (!ok) return 0.f;
+  float v = p.A[(size_t)(pixbase + h * p.srcW + w) * p.ldsrc + c];
+  if (p.pro_scale) {
+    v = v * p.pro_scale[c] + p.pro_shift[c];
+    if (p.pro_relu) v = fmaxf(v, 0.f);
+  }
+  return v;
+}
+
+template <int BM, int BN, int WM, int WN, int AM, int BMD>
+__global__ __launch_bounds__(256) void dj_igemm_kernel(const DjIgemmParams p) {
+  using Cfg = DjIgemmCfg<BM, BN, WM, WN, AM, BMD>;
+  constexpr int TM = Cfg::TM, TN = Cfg::TN, NA = Cfg::NA, NB = Cfg::NB;
+  constexpr int LDA_S = Cfg::LDA_S, LDB_S = Cfg::LDB_S;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tile_m = blockIdx.x / tiles_n;
+  const int tile_n = blockIdx.x - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kbeg = blockIdx.y * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
+  const int nk = (kend - kbeg + DJ_BK - 1) / DJ_BK;
+
+  // ---------------- per-thread staging state ----------------
+  // A, k-contiguous tiles (modes 0/1): thread -> (row r0 + 32 j, 16-byte chunk ac)
+  const int ac = tid & 7, ar0 = tid >> 3;
+  int a_pix[NA], a_rh[NA], a_rw[NA];
+  // A, m-contiguous tiles (mode 2): thread -> (k row akr0 + AKSTEP j, chunk acm)
+  constexpr int AKSTEP = 1024 / BM;
+  const int acm = tid % (BM / 4), akr0 = tid / (BM / 4);
+  int a2_c = 0, a2_dh = 0, a2_dw = 0;
+  bool a2_ok = false;
+  f32x4 a2_sc = {1.f, 1.f, 1.f, 1.f}, a2_sh = {0.f, 0.f, 0.f, 0.f};
+  if (AM != 2) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      int m = m0 + ar0 + 32 * j;
+      if (m < p.M) {
+        int img = m / (p.rowH * p.rowW);
+        int rem = m - img * (p.rowH * p.rowW);
+        int h = rem / p.rowW;
+        int w = rem - h * p.rowW;
+        a_pix[j] = img * p.srcH * p.srcW;
+        if (AM == 0) {
+          a_rh[j] = h * p.sH - p.pT;
+          a_rw[j] = w * p.sW - p.pL;
+        } else {
+          a_rh[j] = h + p.pT;
+          a_rw[j] = w + p.pL;
+        }
+      } else {
+        a_pix[j] = 0;
+        a_rh[j] = -(1 << 28);
+        a_rw[j] = -(1 << 28);
+      }
+    }
+  } else {
+    int mm = m0 + 4 * acm;
+    a2_ok = mm < p.M;
+    int tap = mm / p.srcC;
+    a2_c = mm - tap * p.srcC;
+    int kh = tap / p.KW;
+    int kw = tap - kh * p.KW;
+    a2_dh = kh * p.dH - p.pT;
+    a2_dw = kw * p.dW - p.pL;
+    if (a2_ok && p.pro_scale && p.vecA) {
+      a2_sc = dj_ld4(p.pro_scale + a2_c);
+      a2_sh = dj_ld4(p.pro_shift + a2_c);
+    }
+  }
+  // B, n-contiguous tiles (mode 0): thread -> (k row bkr0 + BKSTEP j, chunk bcn)
+  constexpr int BKSTEP = 1024 / BN;
+  const int bcn = tid % (BN / 4), bkr0 = tid / (BN / 4);
+  // B, k-contiguous tiles (mode 1): thread -> (row n = br0 + 32 j, chunk bc)
+  const int bc = tid & 7, br0 = tid >> 3;
+
+  f32x4 ra[NA], rb[NB];
+
+  auto load_tiles = [&](int kcur) {
+    // ---- A ----
+    if (AM != 2) {
+      int k = kcur + 4 * ac;
+      if (p.vecA) {
+        bool kok = k < kend;
+        int tap = k / p.srcC;
+        int c = k - tap * p.srcC;
+        int kh = tap / p.KW;
+        int kw = tap - kh * p.KW;
+        int dh = kh * p.dH, dw = kw * p.dW;
+        f32x4 sc, sh;
+        if (p.pro_scale && kok) {
+          sc = dj_ld4(p.pro_scale + c);
+          sh = dj_ld4(p.pro_shift + c);
+        }
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+          int h, w;
+          bool ok;
+          if (AM == 0) {
+            h = a_rh[j] + dh;
+            w = a_rw[j] + dw;
+            ok = kok && (unsigned)h < (unsigned)p.srcH && (unsigned)w < (unsigned)p.srcW;
+          } else {
+            int th = a_rh[j] - dh, tw = a_rw[j] - dw;
+            ok = kok && th >= 0 && tw >= 0;
+            if (p.sH == 1 && p.sW == 1) {
+              h = th;
+              w = tw;
+            } else {
+              h = th / p.sH;
+              w = tw / p.sW;
+              ok = ok && (h * p.sH == th) && (w * p.sW == tw);
+            }
+            ok = ok && h < p.srcH && w < p.srcW;
+          }
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (ok) {
+            v = dj_ld4(p.A + (size_t)(a_pix[j] + h * p.srcW + w) * p.ldsrc + c);
+            if (p.pro_scale) {
+              v = v * sc + sh;
+              if (p.pro_relu) {
+                v.x = fmaxf(v.x, 0.f);
+                v.y = fmaxf(v.y, 0.f);
+                v.z = fmaxf(v.z, 0.f);
+                v.w = fmaxf(v.w, 0.f);
+              }
+            }
+          }
+          ra[j] = v;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+          f32x4 v;
+          v.x = (k + 0 < kend) ? dj_gather_elem<AM>(p, a_pix[j], a_rh[j], a_rw[j], k + 0) : 0.f;
+          v.y = (k + 1 < kend) ? dj_gather_elem<AM>(p, a_pix[j], a_rh[j], a_rw[j], k + 1) : 0.f;
+          v.z = (k + 2 < kend) ? dj_gather_elem<AM>(p, a_pix[j], a_rh[j], a_rw[j], k + 2) : 0.f;
+          v.w = (k + 3 < kend) ? dj_gather_elem<AM>(p, a_pix[j], a_rh[j], a_rw[j], k + 3) : 0.f;
+          ra[j] = v;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        int kp = kcur + akr0 + AKSTEP * j;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (kp < kend && a2_ok) {
+          int img = kp / (p.rowH * p.rowW);
+          int rem = kp - img * (p.rowH * p.rowW);
+          int oh = rem / p.rowW;
+          int ow = rem - oh * p.rowW;
+          int h = oh * p.sH + a2_dh, w = ow * p.sW + a2_dw;
+          if (!p.vecA || ((unsigned)h < (unsigned)p.srcH && (unsigned)w < (unsigned)p.srcW)) {
+            if (p.vecA) {
+              const float* src = p.A + (size_t)((img * p.srcH + h) * p.srcW + w) * p.ldsrc;
+              v = dj_ld4(src + a2_c);
+              if (p.pro_scale) {
+                v = v * a2_sc + a2_sh;
+                if (p.pro_relu) {
+                  v.x = fmaxf(v.x, 0.f);
+                  v.y = fmaxf(v.y, 0.f);
+                  v.z = fmaxf(v.z, 0.f);
+                  v.w = fmaxf(v.w, 0.f);
+                }
+              }
+            } else {
+              // element-wise: each of the 4 rows m'+e has its own (tap, c)
+              float t[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                int mm = m0 + 4 * acm + e;
+                float x = 0.f;
+                if (mm < p.M) {
+                  int tap = mm / p.srcC;
+                  int c = mm - tap * p.srcC;
+                  int kh = tap / p.KW;
+                  int kw = tap - kh * p.KW;
+                  int hh = oh * p.sH + kh * p.dH - p.pT, ww = ow * p.sW + kw * p.dW - p.pL;
+                  if ((unsigned)hh < (unsigned)p.srcH && (unsigned)ww < (unsigned)p.srcW) {
+                    x = p.A[(size_t)((img * p.srcH + hh) * p.srcW + ww) * p.ldsrc + c];
+                    if (p.pro_scale) {
+                      x = x * p.pro_scale[c] + p.pro_shift[c];
+                      if (p.pro_relu) x = fmaxf(x, 0.f);
+                    }
+                  }
+                }
+                t[e] = x;
+              }
+              v.x = t[0];
+              v.y = t[1];
+              v.z = t[2];
+              v.w = t[3];
+            }
+          }
+        }
+        ra[j] = v;
+      }
+    }
+    // ---- B ----
+    if (BMD == 0) {
+      int n = n0 + 4 * bcn;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        int k = kcur + bkr0 + BKSTEP * j;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < kend) {
+          const float* src = p.B + (size_t)k * p.ldb + n;
+          if (p.vecB && n + 3 < p.N) {
+            v = dj_ld4(src);
+          } else {
+            if (n + 0 < p.N) v.x = src[0];
+            if (n + 1 < p.N) v.y = src[1];
+            if (n + 2 < p.N) v.z = src[2];
+            if (n + 3 < p.N) v.w = src[3];
+          }
+        }
+        rb[j] = v;
+      }
+    } else {
+      int k = kcur + 4 * bc;
+      int tap = k / p.srcC;
+      int c = k - tap * p.srcC;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        int n = n0 + br0 + 32 * j;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n < p.N) {
+          if (p.vecB) {
+            if (k < kend) v = dj_ld4(p.B + (size_t)tap * p.bTapStride + (size_t)n * p.ldb + c);
+          } else {
+            float t[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              int ke = k + e;
+              float x = 0.f;
+              if (ke < kend) {
+                int tp = ke / p.srcC;
+                int ce = ke - tp * p.srcC;
+                x = p.B[(size_t)tp * p.bTapStride + (size_t)n * p.ldb + ce];
+              }
+              t[e] = x;
+            }
+            v.x = t[0];
+            v.y = t[1];
+            v.z = t[2];
+            v.w = t[3];
+          }
+        }
+        rb[j] = v;
+      }
+    }
+  };
+
+  auto store_tiles = [&](int buf) {
+    float* sA = smem + buf * Cfg::STAGE_FLOATS;
+    float* sB = sA + Cfg::A_FLOATS;
+    if (AM != 2) {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) *reinterpret_cast<f32x4*>(sA + (ar0 + 32 * j) * LDA_S + 4 * ac) = ra[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) *reinterpret_cast<f32x4*>(sA + (akr0 + AKSTEP * j) * LDA_S + 4 * acm) = ra[j];
+    }
+    if (BMD == 0) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) *reinterpret_cast<f32x4*>(sB + (bkr0 + BKSTEP * j) * LDB_S + 4 * bcn) = rb[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) *reinterpret_cast<f32x4*>(sB + (br0 + 32 * j) * LDB_S + 4 * bc) = rb[j];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto compute = [&](int buf) {
+    const float* sA = smem + buf * Cfg::STAGE_FLOATS;
+    const float* sB = sA + Cfg::A_FLOATS;
+#pragma unroll
+    for (int kk = 0; kk < DJ_BK / 8; ++kk) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        int row = (wm * TM + i) * 32 + l31;
+        if (Cfg::A_KC) {
+          af[i] = *reinterpret_cast<const f32x4*>(sA + row * LDA_S + kk * 8 + lh * 4);
+        } else {
+          const float* q = sA + (kk * 8 + lh * 4) * LDA_S + row;
+          af[i].x = q[0];
+          af[i].y = q[LDA_S];
+          af[i].z = q[2 * LDA_S];
+          af[i].w = q[3 * LDA_S];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        int col = (wn * TN + j) * 32 + l31;
+        if (Cfg::B_KC) {
+          bf[j] = *reinterpret_cast<const f32x4*>(sB + col * LDB_S + kk * 8 + lh * 4);
+        } else {
+          const float* q = sB + (kk * 8 + lh * 4) * LDB_S + col;
+          bf[j].x = q[0];
+          bf[j].y = q[LDB_S];
+          bf[j].z = q[2 * LDB_S];
+          bf[j].w = q[3 * LDB_S];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // ---------------- main loop: register prefetch + LDS double buffer ----------------
+  if (nk > 0) {
+    load_tiles(kbeg);
+    store_tiles(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    bool more = kt + 1 < nk;
+    if (more) load_tiles(kbeg + (kt + 1) * DJ_BK);
+    compute(buf);
+    if (more) store_tiles(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---------------- epilogue ----------------
+  if (p.stats) {
+    // per-column sum and sum of squares of the raw accumulator over this tile's rows
+    float* red = smem;  // [2][WM][BN]
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r];
+          s += v;
+          q += v * v;
+        }
+      s += __shfl_xor(s, 32);
+      q += __shfl_xor(q, 32);
+      if (lh == 0) {
+        int col = (wn * TN + j) * 32 + l31;
+        red[(0 * WM + wm) * BN + col] = s;
+        red[(1 * WM + wm) * BN + col] = q;
+      }
+    }
+    __syncthreads();
+    for (int col = tid; col < BN; col += 256) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {
+        s += red[(0 * WM + w) * BN + col];
+        q += red[(1 * WM + w) * BN + col];
+      }
+      int n = n0 + col;
+      if (n < p.N) {
+        p.stats[((size_t)tile_m * 2 + 0) * p.N + n] = s;
+        p.stats[((size_t)tile_m * 2 + 1) * p.N + n] = q;
+      }
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= p.M) continue;
+      size_t rowoff;
+      if (p.cmap == 0) {
+        rowoff = (size_t)m * p.ldc;
+      } else {
+        int img = m / (p.cgH * p.cgW);
+        int rem = m - img * (p.cgH * p.cgW);
+        int h = rem / p.cgW;
+        int w = rem - h * p.cgW;
+        rowoff = (size_t)((img * p.cH + h * p.cS) * p.cW + w * p.cS) * p.ldc;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        int n = n0 + (wn * TN + j) * 32 + l31;
+        if (n >= p.N) continue;
+        float v = acc[i][j][r];
+        float* dst = p.C + rowoff + n;
+        if (p.atomic) {
+          if (p.bias && blockIdx.y == 0) v += p.bias[n];
+          atomicAdd(dst, v);
+        } else {
+          if (p.bias) v += p.bias[n];
+          if (p.beta) v += *dst;
+          if (p.relu) v = fmaxf(v, 0.f);
+          *dst = v;
+        }
+      }
+    }
+  }
+}

@@ -1,0 +1,103 @@
+"""Tensor-level wrappers over the C ABI (include/dj_hip.h): they take torch CUDA tensors,
+validate layout on the host, and launch on torch's current HIP stream.  No arithmetic
+happens here and there is no fallback path."""
+import math
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check, ptr
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _pixel_ld(t):
+    """Pixel stride (floats) of an NHWC tensor that may be a channel slice of a wider buffer."""
+    assert t.dim() == 4 and t.dtype == torch.float32 and t.is_cuda, "expected float32 CUDA NHWC tensor"
+    b, h, w, c = t.shape
+    ld = t.stride(2) if w > 1 else (t.stride(1) if h > 1 else (t.stride(0) if b > 1 else c))
+    assert t.stride(3) == 1 or c == 1, "channels must be contiguous"
+    assert ld >= c
+    if w > 1:
+        assert t.stride(2) == ld
+    if h > 1:
+        assert t.stride(1) == w * ld, "rows must be dense"
+    if b > 1:
+        assert t.stride(0) == h * w * ld, "images must be dense"
+    return ld
+
+
+def same_padding(in_size, kernel, stride, dilation=1):
+    """TensorFlow 'SAME' rule -> (pad_before, pad_after, out_size)."""
+    out = -(-in_size // stride)
+    total = max((out - 1) * stride + (kernel - 1) * dilation + 1 - in_size, 0)
+    return total // 2, total - total // 2, out
+
+
+def conv_geometry(in_h, in_w, kernel, strides, padding, dilation):
+    """Resolve Keras `padding` into explicit pads and the output size.
+    `padding` is 'valid', 'same' or ((top, bottom), (left, right)) (ZeroPadding2D folded in)."""
+    kh, kw = kernel
+    sh, sw = strides
+    dh, dw = dilation
+    if padding == "same":
+        pt, _, oh = same_padding(in_h, kh, sh, dh)
+        pl, _, ow = same_padding(in_w, kw, sw, dw)
+    else:
+        if padding == "valid":
+            (pt, pb), (pl, pr) = (0, 0), (0, 0)
+        else:
+            (pt, pb), (pl, pr) = padding
+        oh = (in_h + pt + pb - (kh - 1) * dh - 1) // sh + 1
+        ow = (in_w + pl + pr - (kw - 1) * dw - 1) // sw + 1
+    return pt, pl, oh, ow
+
+
+def make_conv_desc(batch, in_h, in_w, in_c, out_c, kernel, strides=(1, 1), padding="valid", dilation=(1, 1),
+                   ld_x=None, ld_y=None):
+    pt, pl, oh, ow = conv_geometry(in_h, in_w, kernel, strides, padding, dilation)
+    return ConvDesc(batch, in_h, in_w, in_c, oh, ow, out_c, kernel[0], kernel[1], strides[0], strides[1],
+                    dilation[0], dilation[1], pt, pl, ld_x or in_c, ld_y or out_c)
+
+
+def _desc_for(desc, x, y):
+    d = ConvDesc()
+    for name, _ in ConvDesc._fields_:
+        setattr(d, name, getattr(desc, name))
+    if x is not None:
+        d.ld_x = _pixel_ld(x)
+        assert tuple(x.shape) == (d.batch, d.in_h, d.in_w, d.in_c), (tuple(x.shape), "vs desc")
+    if y is not None:
+        d.ld_y = _pixel_ld(y)
+        assert tuple(y.shape) == (d.batch, d.out_h, d.out_w, d.out_c), (tuple(y.shape), "vs desc")
+    return d
+
+
+def conv2d_stats_rows(desc):
+    return check(_lib.load().dj_conv2d_fwd_stats_rows(desc), "dj_conv2d_fwd_stats_rows")
+
+
+def conv2d_fwd(desc, x, w, bias, y, pro_scale=None, pro_shift=None, pro_relu=False, relu=False, stats=None):
+    d = _desc_for(desc, x, y)
+    assert w.is_contiguous() and tuple(w.shape) == (d.kernel_h, d.kernel_w, d.in_c, d.out_c)
+    check(_lib.load().dj_conv2d_nhwc_fwd(d, ptr(x), ptr(w), ptr(bias), ptr(y), ptr(pro_scale), ptr(pro_shift),
+                                         int(pro_relu), int(relu), ptr(stats), _stream()), "dj_conv2d_nhwc_fwd")
+    return y
+
+
+def conv2d_dgrad(desc, dy, w, dx, bias=None, beta=False):
+    d = _desc_for(desc, dx, dy)
+    assert w.is_contiguous() and tuple(w.shape) == (d.kernel_h, d.kernel_w, d.in_c, d.out_c)
+    check(_lib.load().dj_conv2d_nhwc_dgrad(d, ptr(dy), ptr(w), ptr(bias), ptr(dx), int(beta), _stream()),
+          "dj_conv2d_nhwc_dgrad")
+    return dx
+
+
+def conv2d_wgrad(desc, x, dy, dw, pro_scale=None, pro_shift=None, pro_relu=False):
+    d = _desc_for(desc, x, dy)
+    assert dw.is_contiguous() and tuple(dw.shape) == (d.kernel_h, d.kernel_w, d.in_c, d.out_c)
+    check(_lib.load().dj_conv2d_nhwc_wgrad(d, ptr(x), ptr(dy), ptr(dw), ptr(pro_scale), ptr(pro_shift),
+                                           int(pro_relu), _stream()), "dj_conv2d_nhwc_wgrad")
+    return dw
