@@ -68,6 +68,95 @@ int dj_conv2d_nhwc_dgrad(const dj_conv2d_desc* d, const float* dy, const float* 
 int dj_conv2d_nhwc_wgrad(const dj_conv2d_desc* d, const float* x, const float* dy, float* dw,
                          const float* pro_scale, const float* pro_shift, int pro_relu, void* stream);
 
+/* ---- blocked column reductions (two-stage, deterministic) ------------------------- */
+/* Rows of the `partial` buffers written by the *_partial / *_reduce entry points for a
+ * [rows][C] operand: partial is [dj_reduce_rows(rows)][2][C] floats. */
+int dj_reduce_rows(long rows);
+/* partial[blk][0][c] = sum x, partial[blk][1][c] = sum x^2 over the block's rows.  Batch statistics of
+ * a BatchNormalization whose input is not a conv output (input BNs, L/models/...resnet.py:446,458,1716). */
+int dj_colstats_partial(const float* x, long rows, int C, int ld, float* partial, void* stream);
+/* partial[blk][0][c] = sum dy (bias gradient of Conv2D / Dense: TF BiasAddGrad). */
+int dj_colsum_partial(const float* dy, long rows, int C, int ld, float* partial, void* stream);
+/* out[c] (+)= sum_blk partial[blk][which][c] (accumulated in double). */
+int dj_colreduce_finalize(const float* partial, int nrows, int C, int which, float* out, int beta, void* stream);
+
+/* ---- keras.layers.BatchNormalization(axis=3) (Keras 2.2.4 defaults eps 1e-3, momentum 0.99) ----
+ * Training forward = statistics (conv epilogue `stats` or dj_colstats_partial) -> dj_bn_train_finalize
+ * -> (scale, shift); the normalisation itself is applied by the consumer (conv prologue or
+ * dj_affine_act).  `conv_bias` (optional) is the bias the producing conv added AFTER its statistics
+ * were taken.  moving_* (optional) are updated in place (variance Bessel-corrected, as
+ * tf.nn.fused_batch_norm reports it). */
+int dj_bn_train_finalize(const float* partial, int nrows, long count, const float* conv_bias, const float* gamma,
+                         const float* beta, float eps, float momentum, float* moving_mean, float* moving_var,
+                         float* scale, float* shift, float* save_mean, float* save_invstd, int C, void* stream);
+/* Inference mode: scale = gamma*rsqrt(moving_var+eps), shift = beta - moving_mean*scale. */
+int dj_bn_infer_coeffs(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
+                       float eps, float* scale, float* shift, int C, void* stream);
+/* y = act(x*scale+shift [+ res*res_scale+res_shift]) -- BatchNormalization apply, Activation('relu'),
+ * Add()+Activation('relu') (L/models/...resnet.py:96-99,160-163) in one pass.  Null scale = identity. */
+int dj_affine_act(const float* x, int ldx, const float* scale, const float* shift, const float* res, int ldres,
+                  const float* res_scale, const float* res_shift, float* y, int ldy, long rows, int C, int relu,
+                  void* stream);
+/* Backward of BN(+ReLU): dy is masked by the ReLU (mask_mode 0 none, 1: y > 0 with y the materialised
+ * ReLU output, 2: z*scale+shift > 0), partial[blk] = (sum dy_m, sum dy_m*xhat). */
+int dj_bn_bwd_reduce(const float* dy, int ld_dy, const float* z, int ld_z, const float* y, int ld_y,
+                     const float* mean, const float* invstd, const float* scale, const float* shift, int mask_mode,
+                     long rows, int C, float* partial, void* stream);
+/* dgamma, dbeta and k0,k1,k2 with dz = k0*dy_m + k1*z + k2. */
+int dj_bn_bwd_finalize(const float* partial, int nrows, long count, const float* gamma, const float* mean,
+                       const float* invstd, float* dgamma, float* dbeta, float* k0, float* k1, float* k2, int C,
+                       void* stream);
+int dj_bn_bwd_apply(const float* dy, int ld_dy, const float* z, int ld_z, const float* y, int ld_y,
+                    const float* scale, const float* shift, int mask_mode, const float* k0, const float* k1,
+                    const float* k2, float* dz, int ld_dz, long rows, int C, void* stream);
+/* dx (+)= dy * [y > 0]  (Activation('relu') gradient; `activation="relu"` convs of the SSD head). */
+int dj_relu_bwd(const float* dy, int ld_dy, const float* y, int ld_y, float* dx, int ld_dx, long rows, int C,
+                int beta, void* stream);
+/* dst[r][c] (+)= src[r][c]: Concatenate / Reshape+Concatenate(axis=1) and their gradients
+ * (L/models/...resnet.py:461,836-879,1713-1714). */
+int dj_copy2d(const float* src, long ld_src, float* dst, long ld_dst, long rows, long cols, int beta, void* stream);
+/* UpSampling2D() nearest x2 (L/models/...resnet.py:1669) written into a channel slice. */
+int dj_upsample2x(const float* x, int ldx, float* y, int ldy, int B, int H, int W, int C, void* stream);
+
+/* ---- L2Normalization (L/keras_layers/keras_layer_L2Normalization.py:61-63) ---- */
+int dj_l2norm_fwd(const float* x, int ldx, const float* gamma, float* y, int ldy, float* rnorm, long rows, int C,
+                  void* stream);
+/* dx (optional, (+)=) and dgamma_partial (optional, [dj_reduce_rows(rows)][2][C], slot 0). */
+int dj_l2norm_bwd(const float* dy, int ld_dy, const float* x, int ldx, const float* gamma, const float* rnorm,
+                  float* dx, int ld_dx, float* dgamma_partial, long rows, int C, int beta, void* stream);
+
+/* ---- MaxPooling2D((3,3), strides=(1,1), padding='same'), `pool5_ssd` (L/models/...resnet.py:481,1110) ---- */
+int dj_maxpool3x3s1_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);
+int dj_maxpool3x3s1_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int beta,
+                        void* stream);
+
+/* ---- Activation('softmax') on the last axis (L/models/...resnet.py:873; Dense(..., softmax)) ---- */
+int dj_softmax_fwd(const float* x, float* y, long rows, int C, void* stream);
+int dj_softmax_bwd(const float* p, const float* dp, long ld_dp, float* dx, long rows, int C, int beta, void* stream);
+
+/* ---- SSDLoss.compute_loss (L/keras_loss_function/keras_ssd_loss.py:98-211) ----
+ * y_true / y_pred: [nbox][n_cls+12] with nbox = batch * boxes-per-image; mining is batch-wide.
+ * out5 = {loss (already the Keras batch mean), n_positive, n_negative_kept, class part, loc part}. */
+long dj_ssd_loss_workspace_floats(long nbox);
+int dj_ssd_loss_fwd(const float* y_true, const float* y_pred, long nbox, int n_cls, int neg_pos_ratio, int n_neg_min,
+                    float alpha, float* workspace, float* out5, void* stream);
+int dj_ssd_loss_bwd(const float* y_true, const float* y_pred, long nbox, int n_cls, float alpha, float upstream,
+                    const float* workspace, const float* out5, float* d_pred, void* stream);
+
+/* ---- keras.losses.categorical_crossentropy on probabilities (C/config/resnet/config_file.py:64) ---- */
+int dj_categorical_crossentropy(const float* y_true, const float* probs, long rows, int C, float upstream,
+                                float* loss_rows, float* d_probs, float* out_mean, void* stream);
+
+/* ---- keras.optimizers.SGD.get_updates (L/training_dct_pascal_j2d_resnet.py:152;
+ * C/config/resnet/config_file.py:58-63) with the l2 kernel_regularizer gradient (2*l2*w) and the
+ * data-parallel 1/world_size folded in.  lr_t = lr / (1 + decay * iterations) is computed by the caller. */
+int dj_sgd_momentum_update(float* param, const float* grad, float* velocity, long n, float lr_t, float momentum,
+                           int nesterov, float l2, float grad_scale, float* sumsq, void* stream);
+
+/* ---- GlobalAveragePooling2D (C/vgg_jpeg_keras/networks/resnet_dct.py:415) ---- */
+int dj_global_avg_pool_fwd(const float* x, float* y, int B, int HW, int C, void* stream);
+int dj_global_avg_pool_bwd(const float* dy, float* dx, int B, int HW, int C, int beta, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,34 @@ SIGNATURES = {
     "dj_conv2d_nhwc_fwd": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, FP, c_int, c_int, FP, c_void_p]),
     "dj_conv2d_nhwc_dgrad": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, c_int, c_void_p]),
     "dj_conv2d_nhwc_wgrad": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, c_int, c_void_p]),
+    "dj_reduce_rows": (c_int, [c_long]),
+    "dj_colstats_partial": (c_int, [FP, c_long, c_int, c_int, FP, c_void_p]),
+    "dj_colsum_partial": (c_int, [FP, c_long, c_int, c_int, FP, c_void_p]),
+    "dj_colreduce_finalize": (c_int, [FP, c_int, c_int, c_int, FP, c_int, c_void_p]),
+    "dj_bn_train_finalize": (c_int, [FP, c_int, c_long, FP, FP, FP, c_float, c_float, FP, FP, FP, FP, FP, FP, c_int,
+                                     c_void_p]),
+    "dj_bn_infer_coeffs": (c_int, [FP, FP, FP, FP, c_float, FP, FP, c_int, c_void_p]),
+    "dj_affine_act": (c_int, [FP, c_int, FP, FP, FP, c_int, FP, FP, FP, c_int, c_long, c_int, c_int, c_void_p]),
+    "dj_bn_bwd_reduce": (c_int, [FP, c_int, FP, c_int, FP, c_int, FP, FP, FP, FP, c_int, c_long, c_int, FP, c_void_p]),
+    "dj_bn_bwd_finalize": (c_int, [FP, c_int, c_long, FP, FP, FP, FP, FP, FP, FP, FP, c_int, c_void_p]),
+    "dj_bn_bwd_apply": (c_int, [FP, c_int, FP, c_int, FP, c_int, FP, FP, c_int, FP, FP, FP, FP, c_int, c_long, c_int,
+                                c_void_p]),
+    "dj_relu_bwd": (c_int, [FP, c_int, FP, c_int, FP, c_int, c_long, c_int, c_int, c_void_p]),
+    "dj_copy2d": (c_int, [FP, c_long, FP, c_long, c_long, c_long, c_int, c_void_p]),
+    "dj_upsample2x": (c_int, [FP, c_int, FP, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dj_l2norm_fwd": (c_int, [FP, c_int, FP, FP, c_int, FP, c_long, c_int, c_void_p]),
+    "dj_l2norm_bwd": (c_int, [FP, c_int, FP, c_int, FP, FP, FP, c_int, FP, c_long, c_int, c_int, c_void_p]),
+    "dj_maxpool3x3s1_fwd": (c_int, [FP, FP, c_int, c_int, c_int, c_int, c_void_p]),
+    "dj_maxpool3x3s1_bwd": (c_int, [FP, FP, FP, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dj_softmax_fwd": (c_int, [FP, FP, c_long, c_int, c_void_p]),
+    "dj_softmax_bwd": (c_int, [FP, FP, c_long, FP, c_long, c_int, c_int, c_void_p]),
+    "dj_ssd_loss_workspace_floats": (c_long, [c_long]),
+    "dj_ssd_loss_fwd": (c_int, [FP, FP, c_long, c_int, c_int, c_int, c_float, FP, FP, c_void_p]),
+    "dj_ssd_loss_bwd": (c_int, [FP, FP, c_long, c_int, c_float, c_float, FP, FP, FP, c_void_p]),
+    "dj_categorical_crossentropy": (c_int, [FP, FP, c_long, c_int, c_float, FP, FP, FP, c_void_p]),
+    "dj_sgd_momentum_update": (c_int, [FP, FP, FP, c_long, c_float, c_float, c_int, c_float, c_float, FP, c_void_p]),
+    "dj_global_avg_pool_fwd": (c_int, [FP, FP, c_int, c_int, c_int, c_void_p]),
+    "dj_global_avg_pool_bwd": (c_int, [FP, FP, c_int, c_int, c_int, c_int, c_void_p]),
 }
 
 

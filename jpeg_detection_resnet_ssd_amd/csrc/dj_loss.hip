@@ -1,0 +1,452 @@
+// Softmax, the SSD multibox loss with batch-wide hard-negative mining, categorical
+// cross-entropy and the Keras-formula SGD update.
+// Reference: localisation_part/keras_loss_function/keras_ssd_loss.py:53-211 (SSDLoss),
+// localisation_part/models/keras_ssd300_dct_j2d_resnet.py:873 (softmax),
+// localisation_part/training_dct_pascal_j2d_resnet.py:152 and
+// classification_part/config/resnet/config_file.py:58-65 (SGD, categorical_crossentropy).
+#include "../../include/dj_hip.h"
+#include "dj_common.h"
+
+static inline int ew_blocks(long total) {
+  long b = (total + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+// ---------------------------------------------------------------------------------
+// softmax over the last axis: one wave per row
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dj_softmax_fwd_kernel(const float* x, float* y, long rows, int C) {
+  long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + row * C;
+  float m = -INFINITY;
+  for (int c = lane; c < C; c += 64) m = fmaxf(m, xr[c]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += expf(xr[c] - m);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  float inv = 1.f / s;
+  float* yr = y + row * C;
+  for (int c = lane; c < C; c += 64) yr[c] = expf(xr[c] - m) * inv;
+}
+
+// dx (+)= p * (dp - sum(dp*p))
+__global__ __launch_bounds__(256) void dj_softmax_bwd_kernel(const float* p, const float* dp, long ld_dp, float* dx,
+                                                              long rows, int C, int beta) {
+  long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* pr = p + row * C;
+  const float* gr = dp + row * ld_dp;
+  float dot = 0.f;
+  for (int c = lane; c < C; c += 64) dot += pr[c] * gr[c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+  float* dr = dx + row * C;
+  for (int c = lane; c < C; c += 64) {
+    float v = pr[c] * (gr[c] - dot);
+    dr[c] = beta ? dr[c] + v : v;
+  }
+}
+
+extern "C" int dj_softmax_fwd(const float* x, float* y, long rows, int C, void* stream) {
+  DJ_CHECK_ARG(x && y && rows > 0 && C > 0, "softmax_fwd: bad arguments");
+  hipLaunchKernelGGL(dj_softmax_fwd_kernel, dim3((unsigned)dj_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, y,
+                     rows, C);
+  DJ_CHECK_LAUNCH("dj_softmax_fwd");
+  return DJ_OK;
+}
+
+extern "C" int dj_softmax_bwd(const float* p, const float* dp, long ld_dp, float* dx, long rows, int C, int beta,
+                              void* stream) {
+  DJ_CHECK_ARG(p && dp && dx && rows > 0 && C > 0 && ld_dp >= C, "softmax_bwd: bad arguments");
+  hipLaunchKernelGGL(dj_softmax_bwd_kernel, dim3((unsigned)dj_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, p, dp,
+                     ld_dp, dx, rows, C, beta);
+  DJ_CHECK_LAUNCH("dj_softmax_bwd");
+  return DJ_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// SSD multibox loss.  y_true / y_pred rows are [n_cls | 4 loc | 8 ignored].
+//   per-box pass : cls[i] = -sum_c y_c log(max(p_c,1e-15)); loc[i] = smooth-L1; pos; negloss = cls*y_0
+//   mining pass  : keep the k largest negloss over the WHOLE batch,
+//                  k = min(max(ratio*n_pos, n_neg_min), #nonzero negloss); ties by lowest index
+//   result       : out[0] = (sum pos*cls + sum keep*cls + alpha*sum pos*loc) / max(1, n_pos)
+//                  out[1] = n_pos, out[2] = k, out[3] = class part, out[4] = loc part
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dj_ssd_loss_boxes_kernel(const float* y_true, const float* y_pred, long nbox,
+                                                                 int n_cls, float* cls, float* loc, float* pos,
+                                                                 float* negloss, float* partial) {
+  __shared__ float red[3][256];
+  const int W = n_cls + 12;
+  float s_pos = 0.f, s_pc = 0.f, s_pl = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nbox; i += (long)gridDim.x * blockDim.x) {
+    const float* t = y_true + i * W;
+    const float* p = y_pred + i * W;
+    float cl = 0.f, pmax = 0.f;
+    for (int c = 0; c < n_cls; ++c) {
+      float yc = t[c];
+      if (yc != 0.f) cl -= yc * logf(fmaxf(p[c], 1e-15f));
+      if (c >= 1) pmax = (c == 1) ? yc : fmaxf(pmax, yc);
+    }
+    float lo = 0.f;
+    for (int j = 0; j < 4; ++j) {
+      float d = t[n_cls + j] - p[n_cls + j];
+      float a = fabsf(d);
+      lo += (a < 1.f) ? 0.5f * d * d : a - 0.5f;
+    }
+    cls[i] = cl;
+    loc[i] = lo;
+    pos[i] = pmax;
+    negloss[i] = cl * t[0];
+    s_pos += pmax;
+    s_pc += cl * pmax;
+    s_pl += lo * pmax;
+  }
+  red[0][threadIdx.x] = s_pos;
+  red[1][threadIdx.x] = s_pc;
+  red[2][threadIdx.x] = s_pl;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + o];
+      red[1][threadIdx.x] += red[1][threadIdx.x + o];
+      red[2][threadIdx.x] += red[2][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x * 3 + 0] = red[0][0];
+    partial[blockIdx.x * 3 + 1] = red[1][0];
+    partial[blockIdx.x * 3 + 2] = red[2][0];
+  }
+}
+
+#define DJ_MINE_THREADS 1024
+
+// block-wide exclusive prefix sum of one int per thread (1024 threads = 16 waves)
+__device__ __forceinline__ int block_excl_scan(int v, int* wsum, int* total) {
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int w = 0; w < DJ_MINE_THREADS / 64; ++w) {
+    int t = wsum[w];
+    if (w < wave) base += t;
+    tot += t;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + incl - v;
+}
+
+__global__ __launch_bounds__(DJ_MINE_THREADS) void dj_ssd_loss_mine_kernel(
+    const float* cls, const float* negloss, long nbox, const float* partial, int npartial, int neg_pos_ratio,
+    int n_neg_min, float alpha, float* keep, float* out) {
+  __shared__ unsigned hist[256];
+  __shared__ int wsum[DJ_MINE_THREADS / 64];
+  __shared__ double dred[3];
+  __shared__ unsigned s_prefix;
+  __shared__ long s_k;
+  __shared__ long s_need;
+  __shared__ float s_keepsum[DJ_MINE_THREADS / 64];
+  const int tid = threadIdx.x;
+  if (tid < 3) {
+    double s = 0.0;
+    for (int b = 0; b < npartial; ++b) s += (double)partial[b * 3 + tid];
+    dred[tid] = s;
+  }
+  // number of non-zero negative losses
+  int cnt = 0;
+  for (long i = tid; i < nbox; i += DJ_MINE_THREADS) cnt += (negloss[i] != 0.f);
+  int total_nz;
+  block_excl_scan(cnt, wsum, &total_nz);
+  if (tid == 0) {
+    long npos = (long)dred[0];  // tf.to_int32 truncation of the float sum
+    long k = (long)neg_pos_ratio * npos;
+    if (k < n_neg_min) k = n_neg_min;
+    if (k > total_nz) k = total_nz;
+    s_k = k;
+    s_prefix = 0u;
+    s_need = k;
+  }
+  __syncthreads();
+  const long k = s_k;
+  // radix select (descending) of the k-th largest value; negloss >= 0 so float bits order as unsigned
+  if (k > 0) {
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      for (int j = tid; j < 256; j += DJ_MINE_THREADS) hist[j] = 0u;
+      __syncthreads();
+      unsigned prefix = s_prefix;
+      unsigned himask = (shift == 24) ? 0u : (0xFFFFFFFFu << (shift + 8));
+      for (long i = tid; i < nbox; i += DJ_MINE_THREADS) {
+        unsigned u = __float_as_uint(negloss[i]);
+        if ((u & himask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        long need = s_need;
+        int d = 255;
+        for (; d > 0; --d) {
+          if ((long)hist[d] >= need) break;
+          need -= hist[d];
+        }
+        s_need = need;
+        s_prefix = prefix | ((unsigned)d << shift);
+      }
+      __syncthreads();
+    }
+  }
+  const unsigned T = s_prefix;  // bits of the k-th largest value
+  long need_eq = s_need;        // how many elements equal to T are kept (lowest indices first)
+  float ksum = 0.f;
+  long taken = 0;
+  for (long base = 0; base < nbox; base += DJ_MINE_THREADS) {
+    long i = base + tid;
+    unsigned u = 0u;
+    float cl = 0.f;
+    bool in = i < nbox;
+    if (in) {
+      u = __float_as_uint(negloss[i]);
+      cl = cls[i];
+    }
+    int eq = (k > 0 && in && u == T) ? 1 : 0;
+    int tot;
+    int rank = block_excl_scan(eq, wsum, &tot);
+    bool kp = k > 0 && in && (u > T || (eq && taken + rank < need_eq));
+    taken += tot;
+    if (in) {
+      keep[i] = kp ? 1.f : 0.f;
+      if (kp) ksum += cl;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ksum += __shfl_xor(ksum, o);
+  if ((tid & 63) == 0) s_keepsum[tid >> 6] = ksum;
+  __syncthreads();
+  if (tid == 0) {
+    double ks = 0.0;
+    for (int w = 0; w < DJ_MINE_THREADS / 64; ++w) ks += (double)s_keepsum[w];
+    double npos = dred[0];
+    double denom = npos > 1.0 ? npos : 1.0;
+    double clsp = dred[1] + ks, locp = dred[2];
+    out[0] = (float)((clsp + (double)alpha * locp) / denom);
+    out[1] = (float)npos;
+    out[2] = (float)k;
+    out[3] = (float)(clsp / denom);
+    out[4] = (float)(locp / denom);
+  }
+}
+
+// d y_pred: classes -w*y_c/p_c [p_c > 1e-15], offsets -pos*alpha*f'(t-p), rest 0; all / max(1,n_pos) * upstream
+__global__ __launch_bounds__(256) void dj_ssd_loss_bwd_kernel(const float* y_true, const float* y_pred,
+                                                               const float* pos, const float* keep, const float* out,
+                                                               long nbox, int n_cls, float alpha, float upstream,
+                                                               float* d_pred) {
+  const int W = n_cls + 12;
+  float npos = out[1];
+  float inv = upstream / fmaxf(npos, 1.f);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nbox; i += (long)gridDim.x * blockDim.x) {
+    const float* t = y_true + i * W;
+    const float* p = y_pred + i * W;
+    float* d = d_pred + i * W;
+    float ps = pos[i];
+    float w = (ps + keep[i]) * inv;
+    for (int c = 0; c < n_cls; ++c) {
+      float pc = p[c];
+      d[c] = (w != 0.f && pc > 1e-15f) ? -w * t[c] / pc : 0.f;
+    }
+    float wl = ps * alpha * inv;
+    for (int j = 0; j < 4; ++j) {
+      float df = t[n_cls + j] - p[n_cls + j];
+      float g = (fabsf(df) < 1.f) ? df : ((df > 0.f) ? 1.f : (df < 0.f ? -1.f : 0.f));
+      d[n_cls + j] = -wl * g;
+    }
+    for (int j = 4; j < 12; ++j) d[n_cls + j] = 0.f;
+  }
+}
+
+#define DJ_LOSS_BLOCKS 512
+
+extern "C" long dj_ssd_loss_workspace_floats(long nbox) { return 5 * nbox + 3 * DJ_LOSS_BLOCKS + 8; }
+
+// workspace layout: cls[nbox] loc[nbox] pos[nbox] negloss[nbox] keep[nbox] partial[3*DJ_LOSS_BLOCKS]
+extern "C" int dj_ssd_loss_fwd(const float* y_true, const float* y_pred, long nbox, int n_cls, int neg_pos_ratio,
+                               int n_neg_min, float alpha, float* workspace, float* out5, void* stream) {
+  DJ_CHECK_ARG(y_true && y_pred && workspace && out5 && nbox > 0 && n_cls > 1, "ssd_loss_fwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  float* cls = workspace;
+  float* loc = cls + nbox;
+  float* pos = loc + nbox;
+  float* negloss = pos + nbox;
+  float* keep = negloss + nbox;
+  float* partial = keep + nbox;
+  int blocks = ew_blocks(nbox);
+  if (blocks > DJ_LOSS_BLOCKS) blocks = DJ_LOSS_BLOCKS;
+  hipLaunchKernelGGL(dj_ssd_loss_boxes_kernel, dim3(blocks), dim3(256), 0, s, y_true, y_pred, nbox, n_cls, cls, loc,
+                     pos, negloss, partial);
+  DJ_CHECK_LAUNCH("dj_ssd_loss_boxes");
+  hipLaunchKernelGGL(dj_ssd_loss_mine_kernel, dim3(1), dim3(DJ_MINE_THREADS), 0, s, cls, negloss, nbox, partial,
+                     blocks, neg_pos_ratio, n_neg_min, alpha, keep, out5);
+  DJ_CHECK_LAUNCH("dj_ssd_loss_mine");
+  return DJ_OK;
+}
+
+extern "C" int dj_ssd_loss_bwd(const float* y_true, const float* y_pred, long nbox, int n_cls, float alpha,
+                               float upstream, const float* workspace, const float* out5, float* d_pred,
+                               void* stream) {
+  DJ_CHECK_ARG(y_true && y_pred && workspace && out5 && d_pred && nbox > 0 && n_cls > 1, "ssd_loss_bwd: bad arguments");
+  const float* pos = workspace + 2 * nbox;
+  const float* keep = workspace + 4 * nbox;
+  hipLaunchKernelGGL(dj_ssd_loss_bwd_kernel, dim3(ew_blocks(nbox)), dim3(256), 0, (hipStream_t)stream, y_true, y_pred,
+                     pos, keep, out5, nbox, n_cls, alpha, upstream, d_pred);
+  DJ_CHECK_LAUNCH("dj_ssd_loss_bwd");
+  return DJ_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// categorical cross-entropy on probabilities (Keras 2.2.4, TF backend): one wave per sample
+//   loss_i = -sum_c y_c log(clip(p_c / sum p, 1e-7, 1-1e-7)); out[0] = mean_i loss_i
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dj_cce_kernel(const float* y_true, const float* p, long rows, int C,
+                                                      float upstream_over_rows, float* loss_rows, float* dp) {
+  long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* pr = p + row * C;
+  const float* tr = y_true + row * C;
+  float S = 0.f;
+  for (int c = lane; c < C; c += 64) S += pr[c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) S += __shfl_xor(S, o);
+  float l = 0.f, gp = 0.f;  // gp = sum_c g_c p_c with g = dL/dp'
+  for (int c = lane; c < C; c += 64) {
+    float q = pr[c] / S;
+    float qc = fminf(fmaxf(q, 1e-7f), 1.f - 1e-7f);
+    float yc = tr[c];
+    if (yc != 0.f) {
+      l -= yc * logf(qc);
+      if (q > 1e-7f && q < 1.f - 1e-7f) gp += (-yc / qc) * pr[c];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    l += __shfl_xor(l, o);
+    gp += __shfl_xor(gp, o);
+  }
+  if (lane == 0) loss_rows[row] = l;
+  if (dp) {
+    float* dr = dp + row * C;
+    for (int c = lane; c < C; c += 64) {
+      float q = pr[c] / S;
+      float qc = fminf(fmaxf(q, 1e-7f), 1.f - 1e-7f);
+      float g = (tr[c] != 0.f && q > 1e-7f && q < 1.f - 1e-7f) ? -tr[c] / qc : 0.f;
+      dr[c] = (g / S - gp / (S * S)) * upstream_over_rows;
+    }
+  }
+}
+
+__global__ void dj_mean_kernel(const float* v, long n, float* out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (long i = threadIdx.x; i < n; i += 256) s += (double)v[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)(red[0] / (double)n);
+}
+
+extern "C" int dj_categorical_crossentropy(const float* y_true, const float* probs, long rows, int C, float upstream,
+                                           float* loss_rows, float* d_probs, float* out_mean, void* stream) {
+  DJ_CHECK_ARG(y_true && probs && loss_rows && out_mean && rows > 0 && C > 0, "cce: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(dj_cce_kernel, dim3((unsigned)dj_cdiv(rows, 4)), dim3(256), 0, s, y_true, probs, rows, C,
+                     upstream / (float)rows, loss_rows, d_probs);
+  DJ_CHECK_LAUNCH("dj_cce");
+  hipLaunchKernelGGL(dj_mean_kernel, dim3(1), dim3(256), 0, s, loss_rows, rows, out_mean);
+  DJ_CHECK_LAUNCH("dj_mean");
+  return DJ_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// keras.optimizers.SGD:  g' = g*grad_scale + 2*l2*p ; v = momentum*v - lr_t*g' ;
+//                        p += nesterov ? momentum*v - lr_t*g' : v
+// Optionally accumulates sum(p^2) (pre-update) into sumsq[0] for the l2 penalty report.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dj_sgd_kernel(float* p, const float* g, float* v, long n, float lr_t,
+                                                      float momentum, int nesterov, float l2, float grad_scale,
+                                                      float* sumsq) {
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float pi = p[i];
+    float gi = g[i] * grad_scale + 2.f * l2 * pi;
+    float vi = momentum * v[i] - lr_t * gi;
+    v[i] = vi;
+    p[i] = nesterov ? pi + momentum * vi - lr_t * gi : pi + vi;
+    acc += pi * pi;
+  }
+  if (sumsq) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sumsq, red[0] + red[1] + red[2] + red[3]);
+  }
+}
+
+extern "C" int dj_sgd_momentum_update(float* param, const float* grad, float* velocity, long n, float lr_t,
+                                      float momentum, int nesterov, float l2, float grad_scale, float* sumsq,
+                                      void* stream) {
+  DJ_CHECK_ARG(param && grad && velocity && n > 0, "sgd: bad arguments");
+  hipLaunchKernelGGL(dj_sgd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, param, grad, velocity, n,
+                     lr_t, momentum, nesterov, l2, grad_scale, sumsq);
+  DJ_CHECK_LAUNCH("dj_sgd_momentum_update");
+  return DJ_OK;
+}
+
+// mean over H*W of an NHWC tensor (GlobalAveragePooling2D) and its gradient
+__global__ __launch_bounds__(256) void dj_gap_fwd_kernel(const float* x, float* y, int B, int HW, int C) {
+  long total = (long)B * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    long b = i / C;
+    float s = 0.f;
+    for (int q = 0; q < HW; ++q) s += x[(b * HW + q) * C + c];
+    y[i] = s / (float)HW;
+  }
+}
+__global__ __launch_bounds__(256) void dj_gap_bwd_kernel(const float* dy, float* dx, int B, int HW, int C, int beta) {
+  long total = (long)B * HW * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    long b = i / ((long)HW * C);
+    float v = dy[b * C + c] / (float)HW;
+    dx[i] = beta ? dx[i] + v : v;
+  }
+}
+extern "C" int dj_global_avg_pool_fwd(const float* x, float* y, int B, int HW, int C, void* stream) {
+  DJ_CHECK_ARG(x && y && B > 0 && HW > 0 && C > 0, "gap fwd: bad arguments");
+  hipLaunchKernelGGL(dj_gap_fwd_kernel, dim3(ew_blocks((long)B * C)), dim3(256), 0, (hipStream_t)stream, x, y, B, HW, C);
+  DJ_CHECK_LAUNCH("dj_global_avg_pool_fwd");
+  return DJ_OK;
+}
+extern "C" int dj_global_avg_pool_bwd(const float* dy, float* dx, int B, int HW, int C, int beta, void* stream) {
+  DJ_CHECK_ARG(dy && dx && B > 0 && HW > 0 && C > 0, "gap bwd: bad arguments");
+  hipLaunchKernelGGL(dj_gap_bwd_kernel, dim3(ew_blocks((long)B * HW * C)), dim3(256), 0, (hipStream_t)stream, dy, dx, B,
+                     HW, C, beta);
+  DJ_CHECK_LAUNCH("dj_global_avg_pool_bwd");
+  return DJ_OK;
+}

@@ -1,0 +1,602 @@
+// BatchNormalization (training / inference), ReLU, residual add, L2Normalization and the
+// blocked column reductions they share.  All HBM-bound: 16-byte coalesced accesses,
+// two-stage deterministic reductions (per-block partials, then a per-channel finalize in
+// double precision).  Reference call sites: keras.layers.BatchNormalization(axis=3) at
+// localisation_part/models/keras_ssd300_dct_j2d_resnet.py:80,90,96,135,145,151,160,446,458,1716;
+// Add + Activation('relu') :98-99,162-163; L2Normalization
+// localisation_part/keras_layers/keras_layer_L2Normalization.py:61-63.
+#include "../../include/dj_hip.h"
+#include "dj_common.h"
+
+#define DJ_RB 64  // rows per reduction block
+
+// ---------------------------------------------------------------------------------
+// Blocked column reduction: out[blk][q][c] = sum over the block's rows of f_q(row, c), q in {0,1}
+// ---------------------------------------------------------------------------------
+struct ColStatsF {  // (x, x^2)
+  const float* x;
+  int ld;
+  __device__ __forceinline__ void operator()(long r, int c, float& v0, float& v1) const {
+    float v = x[r * ld + c];
+    v0 = v;
+    v1 = v * v;
+  }
+};
+
+// dy masked by a ReLU, and dy*xhat.  mask_mode 0: none; 1: relu output tensor `y` > 0;
+// 2: own affine z*scale+shift > 0.
+struct BnBwdF {
+  const float* dy;
+  int ld_dy;
+  const float* z;
+  int ld_z;
+  const float* y;
+  int ld_y;
+  const float* mean;
+  const float* invstd;
+  const float* scale;
+  const float* shift;
+  int mask_mode;
+  __device__ __forceinline__ void operator()(long r, int c, float& v0, float& v1) const {
+    float g = dy[r * ld_dy + c];
+    float zz = z[r * ld_z + c];
+    if (mask_mode == 1) {
+      if (!(y[r * ld_y + c] > 0.f)) g = 0.f;
+    } else if (mask_mode == 2) {
+      if (!(zz * scale[c] + shift[c] > 0.f)) g = 0.f;
+    }
+    v0 = g;
+    v1 = g * (zz - mean[c]) * invstd[c];
+  }
+};
+
+// dy * x * rnorm[row]  (dgamma of L2Normalization), second slot unused
+struct L2DgF {
+  const float* dy;
+  const float* x;
+  const float* rnorm;
+  int ld_dy, ld_x;
+  __device__ __forceinline__ void operator()(long r, int c, float& v0, float& v1) const {
+    v0 = dy[r * ld_dy + c] * x[r * ld_x + c] * rnorm[r];
+    v1 = 0.f;
+  }
+};
+
+// plain column sum of dy (bias gradients)
+struct ColSumF {
+  const float* dy;
+  int ld;
+  __device__ __forceinline__ void operator()(long r, int c, float& v0, float& v1) const {
+    v0 = dy[r * ld + c];
+    v1 = 0.f;
+  }
+};
+
+// block = 256 threads as (TX columns) x (256/TX rows); grid = (row blocks, column blocks)
+template <typename F>
+__global__ __launch_bounds__(256) void dj_colreduce_kernel(F f, long rows, int C, int tx_log2, float* partial) {
+  __shared__ float red[2][256];
+  const int TX = 1 << tx_log2;
+  const int TY = 256 >> tx_log2;
+  const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x >> tx_log2;
+  const int c = blockIdx.y * TX + tx;
+  const long r0 = (long)blockIdx.x * DJ_RB;
+  const long r1 = (r0 + DJ_RB < rows) ? r0 + DJ_RB : rows;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < C) {
+    for (long r = r0 + ty; r < r1; r += TY) {
+      float a, b;
+      f(r, c, a, b);
+      s0 += a;
+      s1 += b;
+    }
+  }
+  red[0][threadIdx.x] = s0;
+  red[1][threadIdx.x] = s1;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    for (int j = 1; j < TY; ++j) {
+      s0 += red[0][j * TX + tx];
+      s1 += red[1][j * TX + tx];
+    }
+    partial[((size_t)blockIdx.x * 2 + 0) * C + c] = s0;
+    partial[((size_t)blockIdx.x * 2 + 1) * C + c] = s1;
+  }
+}
+
+template <typename F>
+static int launch_colreduce(F f, long rows, int C, float* partial, hipStream_t s, const char* name) {
+  int tx_log2 = 6;
+  while (tx_log2 > 2 && (1 << (tx_log2 - 1)) >= C) --tx_log2;
+  int TX = 1 << tx_log2;
+  dim3 grid((unsigned)dj_cdiv(rows, DJ_RB), (unsigned)dj_cdiv(C, TX));
+  hipLaunchKernelGGL(dj_colreduce_kernel<F>, grid, dim3(256), 0, s, f, rows, C, tx_log2, partial);
+  DJ_CHECK_LAUNCH(name);
+  return DJ_OK;
+}
+
+extern "C" int dj_reduce_rows(long rows) { return dj_cdiv(rows, DJ_RB); }
+
+extern "C" int dj_colstats_partial(const float* x, long rows, int C, int ld, float* partial, void* stream) {
+  DJ_CHECK_ARG(x && partial && rows > 0 && C > 0 && ld >= C, "colstats: bad arguments");
+  ColStatsF f{x, ld};
+  return launch_colreduce(f, rows, C, partial, (hipStream_t)stream, "dj_colstats_partial");
+}
+
+extern "C" int dj_colsum_partial(const float* dy, long rows, int C, int ld, float* partial, void* stream) {
+  DJ_CHECK_ARG(dy && partial && rows > 0 && C > 0 && ld >= C, "colsum: bad arguments");
+  ColSumF f{dy, ld};
+  return launch_colreduce(f, rows, C, partial, (hipStream_t)stream, "dj_colsum_partial");
+}
+
+// out[c] (+)= sum_r partial[r][which][c]
+__global__ void dj_colreduce_finalize_kernel(const float* partial, int nrows, int C, int which, float* out,
+                                             int beta) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int r = 0; r < nrows; ++r) s += (double)partial[((size_t)r * 2 + which) * C + c];
+  float v = (float)s;
+  if (beta) v += out[c];
+  out[c] = v;
+}
+
+extern "C" int dj_colreduce_finalize(const float* partial, int nrows, int C, int which, float* out, int beta,
+                                     void* stream) {
+  DJ_CHECK_ARG(partial && out && nrows > 0 && C > 0 && (which == 0 || which == 1), "colreduce_finalize: bad arguments");
+  hipLaunchKernelGGL(dj_colreduce_finalize_kernel, dim3(dj_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, partial,
+                     nrows, C, which, out, beta);
+  DJ_CHECK_LAUNCH("dj_colreduce_finalize");
+  return DJ_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// BatchNormalization, training mode: finalize statistics -> (scale, shift)
+// ---------------------------------------------------------------------------------
+__global__ void dj_bn_train_finalize_kernel(const float* partial, int nrows, double count, const float* conv_bias,
+                                            const float* gamma, const float* beta, float eps, float momentum,
+                                            float* moving_mean, float* moving_var, float* scale, float* shift,
+                                            float* save_mean, float* save_invstd, int C) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int r = 0; r < nrows; ++r) {
+    s += (double)partial[((size_t)r * 2 + 0) * C + c];
+    q += (double)partial[((size_t)r * 2 + 1) * C + c];
+  }
+  double m = s / count;
+  double var = q / count - m * m;
+  if (var < 0.0) var = 0.0;
+  // the partials were taken on the conv accumulator before its bias: shift the mean only
+  double mean = m + (conv_bias ? (double)conv_bias[c] : 0.0);
+  float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  save_mean[c] = (float)mean;
+  save_invstd[c] = invstd;
+  if (moving_mean) {
+    double unbiased = var * (count / (count > 1.0 ? count - 1.0 : 1.0));
+    moving_mean[c] = moving_mean[c] * momentum + (float)mean * (1.f - momentum);
+    moving_var[c] = moving_var[c] * momentum + (float)unbiased * (1.f - momentum);
+  }
+}
+
+extern "C" int dj_bn_train_finalize(const float* partial, int nrows, long count, const float* conv_bias,
+                                    const float* gamma, const float* beta, float eps, float momentum,
+                                    float* moving_mean, float* moving_var, float* scale, float* shift,
+                                    float* save_mean, float* save_invstd, int C, void* stream) {
+  DJ_CHECK_ARG(partial && gamma && beta && scale && shift && save_mean && save_invstd, "bn_train_finalize: null");
+  DJ_CHECK_ARG(nrows > 0 && count > 0 && C > 0, "bn_train_finalize: bad sizes");
+  DJ_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "bn_train_finalize: moving stats come together");
+  hipLaunchKernelGGL(dj_bn_train_finalize_kernel, dim3(dj_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, partial,
+                     nrows, (double)count, conv_bias, gamma, beta, eps, momentum, moving_mean, moving_var, scale,
+                     shift, save_mean, save_invstd, C);
+  DJ_CHECK_LAUNCH("dj_bn_train_finalize");
+  return DJ_OK;
+}
+
+__global__ void dj_bn_infer_coeffs_kernel(const float* gamma, const float* beta, const float* moving_mean,
+                                          const float* moving_var, float eps, float* scale, float* shift, int C) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float sc = gamma[c] * rsqrtf(moving_var[c] + eps);
+  scale[c] = sc;
+  shift[c] = beta[c] - moving_mean[c] * sc;
+}
+
+extern "C" int dj_bn_infer_coeffs(const float* gamma, const float* beta, const float* moving_mean,
+                                  const float* moving_var, float eps, float* scale, float* shift, int C,
+                                  void* stream) {
+  DJ_CHECK_ARG(gamma && beta && moving_mean && moving_var && scale && shift && C > 0, "bn_infer_coeffs: bad arguments");
+  hipLaunchKernelGGL(dj_bn_infer_coeffs_kernel, dim3(dj_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, gamma, beta,
+                     moving_mean, moving_var, eps, scale, shift, C);
+  DJ_CHECK_LAUNCH("dj_bn_infer_coeffs");
+  return DJ_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// y = act(x*scale + shift [+ res*res_scale + res_shift]); scale/shift may be null (identity)
+// ---------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void dj_affine_act_kernel(const float* x, int ldx, const float* scale,
+                                                             const float* shift, const float* res, int ldres,
+                                                             const float* rscale, const float* rshift, float* y,
+                                                             int ldy, long rows, int C, int relu) {
+  const int cv = C / VEC;
+  long total = rows * cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i / cv;
+    int c = (int)(i - r * cv) * VEC;
+    float v[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = x[r * ldx + c + e];
+    if (scale) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] = v[e] * scale[c + e] + shift[c + e];
+    }
+    if (res) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float t = res[r * ldres + c + e];
+        if (rscale) t = t * rscale[c + e] + rshift[c + e];
+        v[e] += t;
+      }
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) y[r * ldy + c + e] = v[e];
+  }
+}
+
+static inline int ew_blocks(long total) {
+  long b = (total + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+extern "C" int dj_affine_act(const float* x, int ldx, const float* scale, const float* shift, const float* res,
+                             int ldres, const float* res_scale, const float* res_shift, float* y, int ldy,
+                             long rows, int C, int relu, void* stream) {
+  DJ_CHECK_ARG(x && y && rows > 0 && C > 0 && ldx >= C && ldy >= C, "affine_act: bad arguments");
+  DJ_CHECK_ARG((scale == nullptr) == (shift == nullptr) && (res_scale == nullptr) == (res_shift == nullptr),
+               "affine_act: scale/shift come together");
+  DJ_CHECK_ARG(res || !res_scale, "affine_act: res_scale without res");
+  hipStream_t s = (hipStream_t)stream;
+  bool v4 = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (!res || ldres % 4 == 0);
+  if (v4) {
+    hipLaunchKernelGGL(dj_affine_act_kernel<4>, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, s, x, ldx, scale, shift,
+                       res, ldres, res_scale, res_shift, y, ldy, rows, C, relu);
+  } else {
+    hipLaunchKernelGGL(dj_affine_act_kernel<1>, dim3(ew_blocks(rows * C)), dim3(256), 0, s, x, ldx, scale, shift, res,
+                       ldres, res_scale, res_shift, y, ldy, rows, C, relu);
+  }
+  DJ_CHECK_LAUNCH("dj_affine_act");
+  return DJ_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// BatchNormalization backward
+// ---------------------------------------------------------------------------------
+extern "C" int dj_bn_bwd_reduce(const float* dy, int ld_dy, const float* z, int ld_z, const float* y, int ld_y,
+                                const float* mean, const float* invstd, const float* scale, const float* shift,
+                                int mask_mode, long rows, int C, float* partial, void* stream) {
+  DJ_CHECK_ARG(dy && z && mean && invstd && partial && rows > 0 && C > 0, "bn_bwd_reduce: bad arguments");
+  DJ_CHECK_ARG(mask_mode >= 0 && mask_mode <= 2, "bn_bwd_reduce: mask_mode");
+  DJ_CHECK_ARG(mask_mode != 1 || y, "bn_bwd_reduce: mask_mode 1 needs y");
+  DJ_CHECK_ARG(mask_mode != 2 || (scale && shift), "bn_bwd_reduce: mask_mode 2 needs scale/shift");
+  BnBwdF f{dy, ld_dy, z, ld_z, y, ld_y, mean, invstd, scale, shift, mask_mode};
+  return launch_colreduce(f, rows, C, partial, (hipStream_t)stream, "dj_bn_bwd_reduce");
+}
+
+// dgamma, dbeta and the coefficients of dz = k0*dy_masked + k1*z + k2
+__global__ void dj_bn_bwd_finalize_kernel(const float* partial, int nrows, double count, const float* gamma,
+                                          const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                                          float* k0, float* k1, float* k2, int C) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double sb = 0.0, sg = 0.0;
+  for (int r = 0; r < nrows; ++r) {
+    sb += (double)partial[((size_t)r * 2 + 0) * C + c];
+    sg += (double)partial[((size_t)r * 2 + 1) * C + c];
+  }
+  dbeta[c] = (float)sb;
+  dgamma[c] = (float)sg;
+  double is = (double)invstd[c], sc = (double)gamma[c] * is;
+  double c1 = sb / count, c2 = sg / count;
+  k0[c] = (float)sc;
+  k1[c] = (float)(-sc * c2 * is);
+  k2[c] = (float)(-sc * c1 + sc * c2 * (double)mean[c] * is);
+}
+
+extern "C" int dj_bn_bwd_finalize(const float* partial, int nrows, long count, const float* gamma, const float* mean,
+                                  const float* invstd, float* dgamma, float* dbeta, float* k0, float* k1, float* k2,
+                                  int C, void* stream) {
+  DJ_CHECK_ARG(partial && gamma && mean && invstd && dgamma && dbeta && k0 && k1 && k2, "bn_bwd_finalize: null");
+  DJ_CHECK_ARG(nrows > 0 && count > 0 && C > 0, "bn_bwd_finalize: bad sizes");
+  hipLaunchKernelGGL(dj_bn_bwd_finalize_kernel, dim3(dj_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, partial,
+                     nrows, (double)count, gamma, mean, invstd, dgamma, dbeta, k0, k1, k2, C);
+  DJ_CHECK_LAUNCH("dj_bn_bwd_finalize");
+  return DJ_OK;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void dj_bn_bwd_apply_kernel(const float* dy, int ld_dy, const float* z, int ld_z,
+                                                               const float* y, int ld_y, const float* scale,
+                                                               const float* shift, int mask_mode, const float* k0,
+                                                               const float* k1, const float* k2, float* dz, int ld_dz,
+                                                               long rows, int C) {
+  const int cv = C / VEC;
+  long total = rows * cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i / cv;
+    int c = (int)(i - r * cv) * VEC;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float g = dy[r * ld_dy + c + e];
+      float zz = z[r * ld_z + c + e];
+      if (mask_mode == 1) {
+        if (!(y[r * ld_y + c + e] > 0.f)) g = 0.f;
+      } else if (mask_mode == 2) {
+        if (!(zz * scale[c + e] + shift[c + e] > 0.f)) g = 0.f;
+      }
+      dz[r * ld_dz + c + e] = k0[c + e] * g + k1[c + e] * zz + k2[c + e];
+    }
+  }
+}
+
+extern "C" int dj_bn_bwd_apply(const float* dy, int ld_dy, const float* z, int ld_z, const float* y, int ld_y,
+                               const float* scale, const float* shift, int mask_mode, const float* k0,
+                               const float* k1, const float* k2, float* dz, int ld_dz, long rows, int C,
+                               void* stream) {
+  DJ_CHECK_ARG(dy && z && k0 && k1 && k2 && dz && rows > 0 && C > 0, "bn_bwd_apply: bad arguments");
+  DJ_CHECK_ARG(mask_mode >= 0 && mask_mode <= 2, "bn_bwd_apply: mask_mode");
+  DJ_CHECK_ARG(mask_mode != 1 || y, "bn_bwd_apply: mask_mode 1 needs y");
+  DJ_CHECK_ARG(mask_mode != 2 || (scale && shift), "bn_bwd_apply: mask_mode 2 needs scale/shift");
+  hipStream_t s = (hipStream_t)stream;
+  bool v4 = (C % 4 == 0) && (ld_dy % 4 == 0) && (ld_z % 4 == 0) && (ld_dz % 4 == 0) && (mask_mode != 1 || ld_y % 4 == 0);
+  if (v4)
+    hipLaunchKernelGGL(dj_bn_bwd_apply_kernel<4>, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, s, dy, ld_dy, z, ld_z,
+                       y, ld_y, scale, shift, mask_mode, k0, k1, k2, dz, ld_dz, rows, C);
+  else
+    hipLaunchKernelGGL(dj_bn_bwd_apply_kernel<1>, dim3(ew_blocks(rows * C)), dim3(256), 0, s, dy, ld_dy, z, ld_z, y,
+                       ld_y, scale, shift, mask_mode, k0, k1, k2, dz, ld_dz, rows, C);
+  DJ_CHECK_LAUNCH("dj_bn_bwd_apply");
+  return DJ_OK;
+}
+
+// dx (+)= dy * [y > 0]
+template <int VEC>
+__global__ __launch_bounds__(256) void dj_relu_bwd_kernel(const float* dy, int ld_dy, const float* y, int ld_y,
+                                                           float* dx, int ld_dx, long rows, int C, int beta) {
+  const int cv = C / VEC;
+  long total = rows * cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i / cv;
+    int c = (int)(i - r * cv) * VEC;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float g = (y[r * ld_y + c + e] > 0.f) ? dy[r * ld_dy + c + e] : 0.f;
+      float* d = dx + r * ld_dx + c + e;
+      *d = beta ? (*d + g) : g;
+    }
+  }
+}
+
+extern "C" int dj_relu_bwd(const float* dy, int ld_dy, const float* y, int ld_y, float* dx, int ld_dx, long rows,
+                           int C, int beta, void* stream) {
+  DJ_CHECK_ARG(dy && y && dx && rows > 0 && C > 0, "relu_bwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  bool v4 = (C % 4 == 0) && (ld_dy % 4 == 0) && (ld_y % 4 == 0) && (ld_dx % 4 == 0);
+  if (v4)
+    hipLaunchKernelGGL(dj_relu_bwd_kernel<4>, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, s, dy, ld_dy, y, ld_y, dx,
+                       ld_dx, rows, C, beta);
+  else
+    hipLaunchKernelGGL(dj_relu_bwd_kernel<1>, dim3(ew_blocks(rows * C)), dim3(256), 0, s, dy, ld_dy, y, ld_y, dx, ld_dx,
+                       rows, C, beta);
+  DJ_CHECK_LAUNCH("dj_relu_bwd");
+  return DJ_OK;
+}
+
+// dst[r][c] (+)= src[r][c]   (Concatenate / its gradient / Reshape+Concatenate(axis=1))
+template <int VEC>
+__global__ __launch_bounds__(256) void dj_copy2d_kernel(const float* src, long lds, float* dst, long ldd, long rows,
+                                                         long cols, int beta) {
+  const long cv = cols / VEC;
+  long total = rows * cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i / cv;
+    long c = (i - r * cv) * VEC;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float v = src[r * lds + c + e];
+      float* d = dst + r * ldd + c + e;
+      *d = beta ? (*d + v) : v;
+    }
+  }
+}
+
+extern "C" int dj_copy2d(const float* src, long ld_src, float* dst, long ld_dst, long rows, long cols, int beta,
+                         void* stream) {
+  DJ_CHECK_ARG(src && dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= cols, "copy2d: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  bool v4 = (cols % 4 == 0) && (ld_src % 4 == 0) && (ld_dst % 4 == 0);
+  if (v4)
+    hipLaunchKernelGGL(dj_copy2d_kernel<4>, dim3(ew_blocks(rows * (cols / 4))), dim3(256), 0, s, src, ld_src, dst,
+                       ld_dst, rows, cols, beta);
+  else
+    hipLaunchKernelGGL(dj_copy2d_kernel<1>, dim3(ew_blocks(rows * cols)), dim3(256), 0, s, src, ld_src, dst, ld_dst,
+                       rows, cols, beta);
+  DJ_CHECK_LAUNCH("dj_copy2d");
+  return DJ_OK;
+}
+
+// UpSampling2D() nearest x2: y[b, 2i+a, 2j+c, :] = x[b, i, j, :]
+__global__ __launch_bounds__(256) void dj_upsample2x_kernel(const float* x, int ldx, float* y, int ldy, int B, int H,
+                                                             int W, int C) {
+  long total = (long)B * 2 * H * 2 * W * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    long p = i / C;
+    int ow = (int)(p % (2 * W));
+    long q = p / (2 * W);
+    int oh = (int)(q % (2 * H));
+    int b = (int)(q / (2 * H));
+    y[p * ldy + c] = x[((long)(b * H + oh / 2) * W + ow / 2) * ldx + c];
+  }
+}
+
+extern "C" int dj_upsample2x(const float* x, int ldx, float* y, int ldy, int B, int H, int W, int C, void* stream) {
+  DJ_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && C > 0 && ldx >= C && ldy >= C, "upsample2x: bad arguments");
+  hipLaunchKernelGGL(dj_upsample2x_kernel, dim3(ew_blocks((long)B * 4 * H * W * C)), dim3(256), 0, (hipStream_t)stream,
+                     x, ldx, y, ldy, B, H, W, C);
+  DJ_CHECK_LAUNCH("dj_upsample2x");
+  return DJ_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// L2Normalization: y = x * rsqrt(max(sum_c x^2, 1e-12)) * gamma ; one wave per pixel
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dj_l2norm_fwd_kernel(const float* x, int ldx, const float* gamma, float* y,
+                                                             int ldy, float* rnorm, long rows, int C) {
+  long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + row * ldx;
+  float ss = 0.f;
+  for (int c = lane; c < C; c += 64) ss += xr[c] * xr[c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  float rn = rsqrtf(fmaxf(ss, 1e-12f));
+  if (lane == 0 && rnorm) rnorm[row] = rn;
+  float* yr = y + row * ldy;
+  for (int c = lane; c < C; c += 64) yr[c] = xr[c] * rn * gamma[c];
+}
+
+extern "C" int dj_l2norm_fwd(const float* x, int ldx, const float* gamma, float* y, int ldy, float* rnorm, long rows,
+                             int C, void* stream) {
+  DJ_CHECK_ARG(x && gamma && y && rows > 0 && C > 0, "l2norm_fwd: bad arguments");
+  hipLaunchKernelGGL(dj_l2norm_fwd_kernel, dim3((unsigned)dj_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                     gamma, y, ldy, rnorm, rows, C);
+  DJ_CHECK_LAUNCH("dj_l2norm_fwd");
+  return DJ_OK;
+}
+
+// dx (+)= rn * (g - xhat * sum_c(g*xhat)), g = dy*gamma, xhat = x*rn  (clamped rows: dx = g*rn)
+__global__ __launch_bounds__(256) void dj_l2norm_bwd_kernel(const float* dy, int ld_dy, const float* x, int ldx,
+                                                             const float* gamma, const float* rnorm, float* dx,
+                                                             int ld_dx, long rows, int C, int beta) {
+  long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + row * ldx;
+  const float* gr = dy + row * ld_dy;
+  float rn = rnorm[row];
+  float dot = 0.f;
+  for (int c = lane; c < C; c += 64) dot += gr[c] * gamma[c] * xr[c] * rn;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+  bool clamped = rn >= 1e6f;  // sum(x^2) <= 1e-12: the norm is the constant 1e-6
+  float* dr = dx + row * ld_dx;
+  for (int c = lane; c < C; c += 64) {
+    float g = gr[c] * gamma[c];
+    float v = clamped ? g * rn : rn * (g - xr[c] * rn * dot);
+    dr[c] = beta ? dr[c] + v : v;
+  }
+}
+
+extern "C" int dj_l2norm_bwd(const float* dy, int ld_dy, const float* x, int ldx, const float* gamma,
+                             const float* rnorm, float* dx, int ld_dx, float* dgamma_partial, long rows, int C,
+                             int beta, void* stream) {
+  DJ_CHECK_ARG(dy && x && gamma && rnorm && rows > 0 && C > 0, "l2norm_bwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (dx) {
+    hipLaunchKernelGGL(dj_l2norm_bwd_kernel, dim3((unsigned)dj_cdiv(rows, 4)), dim3(256), 0, s, dy, ld_dy, x, ldx, gamma,
+                       rnorm, dx, ld_dx, rows, C, beta);
+    DJ_CHECK_LAUNCH("dj_l2norm_bwd");
+  }
+  if (dgamma_partial) {
+    L2DgF f{dy, x, rnorm, ld_dy, ldx};
+    return launch_colreduce(f, rows, C, dgamma_partial, s, "dj_l2norm_bwd(dgamma)");
+  }
+  return DJ_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// MaxPooling2D((3,3), strides 1, 'same')  -- pool5_ssd
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dj_maxpool3x3s1_fwd_kernel(const float* x, float* y, int B, int H, int W,
+                                                                   int C) {
+  long total = (long)B * H * W * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    long p = i / C;
+    int w = (int)(p % W);
+    long q = p / W;
+    int h = (int)(q % H);
+    int b = (int)(q / H);
+    float m = -INFINITY;
+    for (int dh = -1; dh <= 1; ++dh)
+      for (int dw = -1; dw <= 1; ++dw) {
+        int hh = h + dh, ww = w + dw;
+        if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W)
+          m = fmaxf(m, x[((long)(b * H + hh) * W + ww) * C + c]);
+      }
+    y[i] = m;
+  }
+}
+
+// gradient goes to the first maximum of each window in row-major window order
+__global__ __launch_bounds__(256) void dj_maxpool3x3s1_bwd_kernel(const float* x, const float* dy, float* dx, int B,
+                                                                   int H, int W, int C, int beta) {
+  long total = (long)B * H * W * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    long p = i / C;
+    int w = (int)(p % W);
+    long q = p / W;
+    int h = (int)(q % H);
+    int b = (int)(q / H);
+    float acc = 0.f;
+    // windows (centres) that contain (h, w)
+    for (int ch = h - 1; ch <= h + 1; ++ch)
+      for (int cw = w - 1; cw <= w + 1; ++cw) {
+        if ((unsigned)ch >= (unsigned)H || (unsigned)cw >= (unsigned)W) continue;
+        float m = -INFINITY;
+        int ah = -1, aw = -1;
+        for (int dh = -1; dh <= 1; ++dh)
+          for (int dw = -1; dw <= 1; ++dw) {
+            int hh = ch + dh, ww = cw + dw;
+            if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) {
+              float v = x[((long)(b * H + hh) * W + ww) * C + c];
+              if (v > m) {
+                m = v;
+                ah = hh;
+                aw = ww;
+              }
+            }
+          }
+        if (ah == h && aw == w) acc += dy[((long)(b * H + ch) * W + cw) * C + c];
+      }
+    dx[i] = beta ? dx[i] + acc : acc;
+  }
+}
+
+extern "C" int dj_maxpool3x3s1_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) {
+  DJ_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && C > 0, "maxpool fwd: bad arguments");
+  hipLaunchKernelGGL(dj_maxpool3x3s1_fwd_kernel, dim3(ew_blocks((long)B * H * W * C)), dim3(256), 0,
+                     (hipStream_t)stream, x, y, B, H, W, C);
+  DJ_CHECK_LAUNCH("dj_maxpool3x3s1_fwd");
+  return DJ_OK;
+}
+
+extern "C" int dj_maxpool3x3s1_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int beta,
+                                   void* stream) {
+  DJ_CHECK_ARG(x && dy && dx && B > 0 && H > 0 && W > 0 && C > 0, "maxpool bwd: bad arguments");
+  hipLaunchKernelGGL(dj_maxpool3x3s1_bwd_kernel, dim3(ew_blocks((long)B * H * W * C)), dim3(256), 0,
+                     (hipStream_t)stream, x, dy, dx, B, H, W, C, beta);
+  DJ_CHECK_LAUNCH("dj_maxpool3x3s1_bwd");
+  return DJ_OK;
+}

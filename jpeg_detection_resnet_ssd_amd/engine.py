@@ -1,0 +1,160 @@
+"""Static execution plans for Keras-style graphs on one MI355X.
+
+A `Plan` is what `Model.compile()/fit_generator()/predict()` run: the layer graph is lowered ONCE
+(per batch size and mode) into a fixed list of C-ABI launches over preallocated HBM buffers --
+forward list, backward list -- so a training step is launch-only (no allocation, no host sync, no
+Python autograd) and can be captured into a hipGraph.  This takes the place of the Keras 2.2.4
+`fit_generator -> train_on_batch -> K.function -> tf.Session.run` stack the reference relies on
+(localisation_part/training_dct_pascal_j2d_resnet.py:330-336).
+
+Tensors inside a plan are `Value`s.  A Value is either materialised (`buf`) or a *virtual*
+per-channel affine(+ReLU) of a raw buffer: BatchNormalization and Activation('relu') do not launch
+anything in the forward pass -- the consumer conv applies `relu(z*scale+shift)` while staging its A
+tile (kernel prologue), and Add+ReLU applies both branches' affines in its single pass.
+
+Backward lists are built in a second pass, in exactly the order they will execute; `Plan.grad_of`
+hands out the gradient buffer of a Value and tells the caller whether it is the first writer
+(store) or a later one (accumulate, `beta=1` epilogues), so fan-out needs no extra add kernels.
+"""
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+def _conv(a):
+    if isinstance(a, torch.Tensor):
+        return a.data_ptr()
+    return a
+
+
+def call(name, *args):
+    """Launch one C-ABI entry point on torch's current HIP stream (tensors -> device pointers)."""
+    fn = getattr(_lib.load(), name)
+    rc = fn(*[_conv(a) for a in args], torch.cuda.current_stream().cuda_stream)
+    check(rc, name)
+
+
+def query(name, *args):
+    return check(getattr(_lib.load(), name)(*args), name)
+
+
+class GradRef(object):
+    """Gradient of a Value: a buffer, optionally to be masked by `mask_y > 0` by whoever reads it
+    (lets Add+ReLU hand its upstream gradient to both branches without materialising the mask)."""
+
+    def __init__(self, buf, mask_y=None):
+        self.buf = buf
+        self.mask_y = mask_y
+
+
+class Value(object):
+    def __init__(self, buf, scale=None, shift=None, relu=False, needs_grad=False, name=""):
+        self.buf = buf
+        self.scale = scale
+        self.shift = shift
+        self.relu = relu
+        self.needs_grad = needs_grad
+        self.name = name
+        self.grad = None          # GradRef, set during the backward-building pass
+        self.alias_of = None      # gradient requests are redirected (ZeroPadding2D, Reshape)
+        self.alias_view = None    # callable: grad buffer of alias_of -> view shaped like self
+        self.pad = None           # pending ZeroPadding2D ((t,b),(l,r)) consumed by the next Conv2D
+        self.conv_stats = None    # (partial, nrows, conv_bias) when the producing conv took BN statistics
+        self.relu_child = None    # Value created by Activation('relu') on a virtual affine
+        self.bn = None            # BatchNormalization record that produced this virtual affine
+
+    @property
+    def is_affine(self):
+        return self.scale is not None
+
+    @property
+    def shape(self):
+        return tuple(self.buf.shape)
+
+
+class Plan(object):
+    def __init__(self, device, batch_size, training):
+        self.device = device
+        self.batch_size = batch_size
+        self.training = training
+        self.fwd = []
+        self.bwd = []
+        self._bwd_builders = []
+        self.values = {}       # KTensor id -> Value
+        self.inputs = []       # device buffers the host copies each batch into
+        self.outputs = []
+        self.y_true = None
+        self.loss_out = None   # device float[5]
+        self.bytes_allocated = 0
+        self.hooks_after_backward = []  # e.g. data-parallel gradient exchange
+
+    # ---- allocation -------------------------------------------------------------
+    def empty(self, *shape):
+        t = torch.empty(*shape, dtype=torch.float32, device=self.device)
+        self.bytes_allocated += t.numel() * 4
+        return t
+
+    def zeros(self, *shape):
+        t = torch.zeros(*shape, dtype=torch.float32, device=self.device)
+        self.bytes_allocated += t.numel() * 4
+        return t
+
+    # ---- recording -------------------------------------------------------------
+    def emit(self, fn):
+        self.fwd.append(fn)
+
+    def emit_bwd(self, fn):
+        self.bwd.append(fn)
+
+    def on_backward(self, builder):
+        """Register a function that appends this op's backward launches; builders run in reverse
+        registration order once the forward lowering is complete."""
+        self._bwd_builders.append(builder)
+
+    def build_backward(self):
+        for b in reversed(self._bwd_builders):
+            b()
+        self._bwd_builders = []
+
+    # ---- gradients ------------------------------------------------------------
+    def grad_of(self, v):
+        """-> (buffer, beta).  beta = 0 for the first writer in backward execution order."""
+        if v.alias_of is not None:
+            buf, beta = self.grad_of(v.alias_of)
+            return v.alias_view(buf), beta
+        if v.grad is None:
+            v.grad = GradRef(self.empty(*v.buf.shape))
+            return v.grad.buf, 0
+        assert v.grad.mask_y is None, "cannot accumulate into a masked gradient reference"
+        return v.grad.buf, 1
+
+    def set_grad_ref(self, v, ref):
+        assert v.alias_of is None and v.grad is None, "gradient of %s already has a writer" % v.name
+        v.grad = ref
+
+    # ---- execution -------------------------------------------------------------
+    def run_forward(self):
+        for f in self.fwd:
+            f()
+
+    def run_backward(self):
+        for f in self.bwd:
+            f()
+        for h in self.hooks_after_backward:
+            h()
+
+
+def rows_of(buf):
+    """(rows, C, ld) of an NHWC / [.., C] buffer that may be a channel slice."""
+    c = buf.shape[-1]
+    rows = buf.numel() // c
+    if buf.dim() >= 2 and buf.shape[-2] > 1:
+        ld = buf.stride(-2)
+    else:
+        ld = c
+        for d in range(buf.dim() - 2, -1, -1):
+            if buf.shape[d] > 1:
+                ld = buf.stride(d)
+                break
+    return rows, c, ld

@@ -1,0 +1,838 @@
+"""Keras-2.2.4-style layers, limited to what the reference's ResNet50-DCT / SSD300 builders use
+(localisation_part/models/keras_ssd300_dct_j2d_resnet.py:22-36,
+classification_part/vgg_jpeg_keras/networks/resnet_dct.py), each with a `lower()` that turns it into
+C-ABI launches inside an engine.Plan.  Same constructor keywords, defaults, auto-naming and
+`_keras_shape` / `output_shape` attributes as Keras, so builder code reads like the reference's."""
+import re
+
+import numpy as np
+import torch
+
+from .. import engine
+from ..engine import GradRef, Value, call, query, rows_of
+from .. import kernels as Kn
+from . import backend as K
+from . import initializers
+
+_SERIAL = [0]
+
+
+def _snake(name):
+    s = re.sub("(.)([A-Z][a-z0-9]+)", r"\1_\2", name)
+    return re.sub("([a-z])([A-Z])", r"\1_\2", s).lower()
+
+
+def _pair(v):
+    if isinstance(v, (list, tuple)):
+        assert len(v) == 2
+        return (int(v[0]), int(v[1]))
+    return (int(v), int(v))
+
+
+class KTensor(object):
+    """Symbolic tensor: static shape with a None batch axis, and the layer that produces it."""
+
+    def __init__(self, shape, layer=None, index=0):
+        self.shape = tuple(shape)
+        self._keras_shape = self.shape
+        self.layer = layer
+        self.index = index
+
+    def __repr__(self):
+        return "<KTensor %s from %s>" % (self.shape, self.layer.name if self.layer else None)
+
+
+class InputSpec(object):
+    def __init__(self, shape=None, ndim=None, dtype=None):
+        self.shape = shape
+        self.ndim = ndim
+        self.dtype = dtype
+
+
+class WeightSpec(object):
+    def __init__(self, layer, name, shape, initializer, trainable, l2):
+        self.layer = layer
+        self.name = name            # Keras weight name inside the layer, e.g. 'kernel'
+        self.shape = tuple(int(s) for s in shape)
+        self.initializer = initializer
+        self.trainable = trainable
+        self.l2 = l2
+        self.param = None           # device tensor (view into the model's flat store)
+        self.grad = None
+        self.init_value = None
+
+    @property
+    def key(self):
+        return "%s/%s" % (self.layer.name, self.name)
+
+    @property
+    def size(self):
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+
+class Layer(object):
+    """Base class following keras.engine.topology.Layer's protocol (build / call /
+    compute_output_shape / get_config), cf. localisation_part/keras_layers/*.py."""
+
+    def __init__(self, name=None, trainable=True, input_shape=None, **kwargs):
+        if kwargs:
+            unknown = set(kwargs) - {"dtype", "batch_input_shape", "weights"}
+            if unknown:
+                raise TypeError("unexpected keyword arguments %s" % sorted(unknown))
+        if not name:
+            prefix = _snake(self.__class__.__name__)
+            name = "%s_%d" % (prefix, K.get_uid(prefix))
+        self.name = name
+        self.trainable = trainable
+        self.built = False
+        self.weight_specs = []
+        self.inbound = None
+        self.outbound = None
+        self.input_spec = None
+        self.serial = None
+
+    # -- Keras protocol ------------------------------------------------------------
+    def build(self, input_shape):
+        self.built = True
+
+    def compute_output_shape(self, input_shape):
+        return input_shape
+
+    def get_config(self):
+        return {"name": self.name, "trainable": self.trainable}
+
+    def add_weight(self, name, shape, initializer="zeros", trainable=True, regularizer=None):
+        spec = WeightSpec(self, name, shape, initializers.get(initializer), trainable and self.trainable,
+                          regularizer.l2 if regularizer is not None else 0.0)
+        self.weight_specs.append(spec)
+        return spec
+
+    @property
+    def weights(self):
+        return list(self.weight_specs)
+
+    @property
+    def trainable_weights(self):
+        return [w for w in self.weight_specs if w.trainable]
+
+    @trainable_weights.setter
+    def trainable_weights(self, value):  # custom layers assign it (L2Normalization.build)
+        pass
+
+    def count_params(self):
+        return sum(w.size for w in self.weight_specs)
+
+    def __call__(self, inputs):
+        if self.inbound is not None:
+            raise NotImplementedError("layer %s called twice: shared layers are not on the reference's path" % self.name)
+        many = isinstance(inputs, (list, tuple))
+        ins = list(inputs) if many else [inputs]
+        for t in ins:
+            if not isinstance(t, KTensor):
+                raise TypeError("layer %s called on a non-tensor %r" % (self.name, t))
+        shape_arg = [t.shape for t in ins] if many else ins[0].shape
+        if not self.built:
+            self.build(shape_arg)
+            self.built = True
+        out_shape = self.compute_output_shape(shape_arg)
+        self.inbound = ins
+        _SERIAL[0] += 1
+        self.serial = _SERIAL[0]
+        out = KTensor(out_shape, self, 0)
+        self.outbound = [out]
+        self.input_shape = shape_arg
+        self.output_shape = tuple(out_shape)
+        return out
+
+    @property
+    def output(self):
+        return self.outbound[0]
+
+    @property
+    def input(self):
+        return self.inbound[0] if len(self.inbound) == 1 else self.inbound
+
+    # -- lowering ---------------------------------------------------------------
+    def lower(self, plan, model, ins):
+        raise NotImplementedError("%s has no MI355X lowering" % self.__class__.__name__)
+
+
+class InputLayer(Layer):
+    def __init__(self, shape, name=None):
+        super(InputLayer, self).__init__(name=name or "input_%d" % K.get_uid("input"))
+        self.shape = (None,) + tuple(shape)
+        self.inbound = []
+        _SERIAL[0] += 1
+        self.serial = _SERIAL[0]
+        self.outbound = [KTensor(self.shape, self, 0)]
+        self.output_shape = self.shape
+        self.input_shape = self.shape
+        self.built = True
+
+    def lower(self, plan, model, ins):
+        buf = plan.empty(plan.batch_size, *self.shape[1:])
+        plan.inputs.append(buf)
+        return Value(buf, needs_grad=False, name=self.name)
+
+
+def Input(shape=None, batch_shape=None, name=None, dtype=None, tensor=None):
+    if shape is None and batch_shape is not None:
+        shape = batch_shape[1:]
+    return InputLayer(tuple(shape), name=name).outbound[0]
+
+
+# =====================================================================================
+# helpers shared by the lowerings
+# =====================================================================================
+def _materialised(v, who):
+    if v.is_affine:
+        raise NotImplementedError("%s cannot consume a virtual BatchNormalization output; "
+                                  "this graph shape is outside the reference's builders" % who)
+    if v.pad is not None:
+        raise NotImplementedError("%s cannot consume a pending ZeroPadding2D" % who)
+    return v.buf
+
+
+def _bias_grad(plan, dy, spec):
+    """dbias = column sum of dy (two-stage)."""
+    rows, c, ld = rows_of(dy)
+    nr = query("dj_reduce_rows", rows)
+    partial = plan.empty(nr, 2, c)
+    plan.emit_bwd(lambda: call("dj_colsum_partial", dy, rows, c, ld, partial))
+    plan.emit_bwd(lambda: call("dj_colreduce_finalize", partial, nr, c, 0, spec.grad, 0))
+
+
+# =====================================================================================
+# Conv2D / Conv2DTranspose / Dense
+# =====================================================================================
+class Conv2D(Layer):
+    """keras.layers.Conv2D(filters, kernel_size, strides=(1,1), padding='valid', dilation_rate=(1,1),
+    activation=None, use_bias=True, kernel_initializer='glorot_uniform', kernel_regularizer=None)."""
+
+    def __init__(self, filters, kernel_size, strides=(1, 1), padding="valid", data_format=None,
+                 dilation_rate=(1, 1), activation=None, use_bias=True, kernel_initializer="glorot_uniform",
+                 bias_initializer="zeros", kernel_regularizer=None, bias_regularizer=None,
+                 activity_regularizer=None, kernel_constraint=None, bias_constraint=None, **kwargs):
+        super(Conv2D, self).__init__(**kwargs)
+        if activation not in (None, "relu", "linear"):
+            raise NotImplementedError("Conv2D activation %r" % (activation,))
+        if padding not in ("valid", "same"):
+            raise ValueError("Invalid border mode for Conv2D: %r" % (padding,))
+        self.filters = int(filters)
+        self.kernel_size = _pair(kernel_size)
+        self.strides = _pair(strides)
+        self.padding = padding
+        self.dilation_rate = _pair(dilation_rate)
+        self.activation = None if activation == "linear" else activation
+        self.use_bias = use_bias
+        self.kernel_initializer = kernel_initializer
+        self.bias_initializer = bias_initializer
+        self.kernel_regularizer = kernel_regularizer
+
+    def build(self, input_shape):
+        cin = input_shape[-1]
+        self.kernel = self.add_weight("kernel", self.kernel_size + (cin, self.filters), self.kernel_initializer,
+                                      regularizer=self.kernel_regularizer)
+        self.bias = self.add_weight("bias", (self.filters,), self.bias_initializer) if self.use_bias else None
+
+    def compute_output_shape(self, input_shape):
+        _, h, w, _ = input_shape
+        _, _, oh, ow = Kn.conv_geometry(h, w, self.kernel_size, self.strides, self.padding, self.dilation_rate)
+        return (input_shape[0], oh, ow, self.filters)
+
+    def lower(self, plan, model, ins):
+        x = ins[0]
+        b, h, w, cin = x.buf.shape
+        padding = self.padding
+        if x.pad is not None:
+            if padding != "valid":
+                raise NotImplementedError("ZeroPadding2D followed by a 'same' Conv2D")
+            padding = x.pad
+        desc = Kn.make_conv_desc(b, h, w, cin, self.filters, self.kernel_size, self.strides, padding,
+                                 self.dilation_rate)
+        y = plan.empty(b, desc.out_h, desc.out_w, self.filters)
+        relu = self.activation == "relu"
+        wgt, bias = self.kernel.param, (self.bias.param if self.bias is not None else None)
+        pro = (x.scale, x.shift, x.relu) if x.is_affine else (None, None, False)
+        stats = None
+        consumers = model.consumers_of(self.outbound[0])
+        if (plan.training and not relu and len(consumers) == 1 and isinstance(consumers[0], BatchNormalization)):
+            nrows = Kn.conv2d_stats_rows(desc)
+            stats = plan.empty(nrows, 2, self.filters)
+        xbuf = x.buf
+        plan.emit(lambda: Kn.conv2d_fwd(desc, xbuf, wgt, bias, y, pro[0], pro[1], pro[2], relu, stats))
+        out = Value(y, needs_grad=True, name=self.name)
+        if stats is not None:
+            out.conv_stats = (stats, stats.shape[0], bias)
+
+        def build_backward():
+            if out.grad is None:
+                return
+            assert out.grad.mask_y is None
+            dy = out.grad.buf
+            if relu:
+                rows, c, ld = rows_of(dy)
+                plan.emit_bwd(lambda: call("dj_relu_bwd", dy, ld, y, c, dy, ld, rows, c, 0))
+            if self.bias is not None and self.bias.trainable:
+                _bias_grad(plan, dy, self.bias)
+            if self.kernel.trainable:
+                dw = self.kernel.grad
+                plan.emit_bwd(lambda: Kn.conv2d_wgrad(desc, xbuf, dy, dw, pro[0], pro[1], pro[2]))
+            if x.needs_grad:
+                dx, beta = plan.grad_of(x)
+                plan.emit_bwd(lambda: Kn.conv2d_dgrad(desc, dy, wgt, dx, None, bool(beta)))
+
+        plan.on_backward(build_backward)
+        return out
+
+
+class Conv2DTranspose(Layer):
+    """keras.layers.Conv2DTranspose(filters, kernel_size, strides), padding 'valid', kernel layout
+    (kh, kw, out, in) (localisation_part/models/keras_ssd300_dct_j2d_resnet.py:1709-1711).
+    Forward = input-gradient kernel of the k x k / stride-s convolution it transposes."""
+
+    def __init__(self, filters, kernel_size, strides=(1, 1), padding="valid", activation=None, use_bias=True,
+                 kernel_initializer="glorot_uniform", bias_initializer="zeros", kernel_regularizer=None, **kwargs):
+        super(Conv2DTranspose, self).__init__(**kwargs)
+        if padding != "valid" or activation not in (None, "linear"):
+            raise NotImplementedError("Conv2DTranspose: only padding='valid', no activation")
+        self.filters = int(filters)
+        self.kernel_size = _pair(kernel_size)
+        self.strides = _pair(strides)
+        self.use_bias = use_bias
+        self.kernel_initializer = kernel_initializer
+        self.bias_initializer = bias_initializer
+        self.kernel_regularizer = kernel_regularizer
+
+    def build(self, input_shape):
+        cin = input_shape[-1]
+        self.kernel = self.add_weight("kernel", self.kernel_size + (self.filters, cin), self.kernel_initializer,
+                                      regularizer=self.kernel_regularizer)
+        self.bias = self.add_weight("bias", (self.filters,), self.bias_initializer) if self.use_bias else None
+
+    def compute_output_shape(self, input_shape):
+        _, h, w, _ = input_shape
+        oh = (h - 1) * self.strides[0] + self.kernel_size[0]
+        ow = (w - 1) * self.strides[1] + self.kernel_size[1]
+        return (input_shape[0], oh, ow, self.filters)
+
+    def lower(self, plan, model, ins):
+        x = ins[0]
+        xbuf = _materialised(x, self.name)
+        b, h, w, cin = xbuf.shape
+        oh = (h - 1) * self.strides[0] + self.kernel_size[0]
+        ow = (w - 1) * self.strides[1] + self.kernel_size[1]
+        # the transposed layer's output is the "input" of the underlying convolution
+        desc = Kn.make_conv_desc(b, oh, ow, self.filters, cin, self.kernel_size, self.strides, "valid", (1, 1))
+        assert (desc.out_h, desc.out_w) == (h, w)
+        y = plan.empty(b, oh, ow, self.filters)
+        wgt, bias = self.kernel.param, (self.bias.param if self.bias is not None else None)
+        plan.emit(lambda: Kn.conv2d_dgrad(desc, xbuf, wgt, y, bias, False))
+        out = Value(y, needs_grad=True, name=self.name)
+
+        def build_backward():
+            if out.grad is None:
+                return
+            assert out.grad.mask_y is None
+            dy = out.grad.buf
+            if self.bias is not None and self.bias.trainable:
+                _bias_grad(plan, dy, self.bias)
+            if self.kernel.trainable:
+                dw = self.kernel.grad
+                plan.emit_bwd(lambda: Kn.conv2d_wgrad(desc, dy, xbuf, dw))
+            if x.needs_grad:
+                dx, beta = plan.grad_of(x)
+                if beta:
+                    raise NotImplementedError("accumulating Conv2DTranspose input gradient")
+                plan.emit_bwd(lambda: Kn.conv2d_fwd(desc, dy, wgt, None, dx))
+
+        plan.on_backward(build_backward)
+        return out
+
+
+class Dense(Layer):
+    """keras.layers.Dense(units, activation) -- `fc1000`
+    (classification_part/vgg_jpeg_keras/networks/resnet_dct.py:417).  Runs as a 1x1 convolution."""
+
+    def __init__(self, units, activation=None, use_bias=True, kernel_initializer="glorot_uniform",
+                 bias_initializer="zeros", kernel_regularizer=None, **kwargs):
+        super(Dense, self).__init__(**kwargs)
+        if activation not in (None, "linear", "softmax", "relu"):
+            raise NotImplementedError("Dense activation %r" % (activation,))
+        self.units = int(units)
+        self.activation = None if activation == "linear" else activation
+        self.use_bias = use_bias
+        self.kernel_initializer = kernel_initializer
+        self.bias_initializer = bias_initializer
+        self.kernel_regularizer = kernel_regularizer
+
+    def build(self, input_shape):
+        self.kernel = self.add_weight("kernel", (input_shape[-1], self.units), self.kernel_initializer,
+                                      regularizer=self.kernel_regularizer)
+        self.bias = self.add_weight("bias", (self.units,), self.bias_initializer) if self.use_bias else None
+
+    def compute_output_shape(self, input_shape):
+        return tuple(input_shape[:-1]) + (self.units,)
+
+    def lower(self, plan, model, ins):
+        x = ins[0]
+        xbuf = _materialised(x, self.name)
+        assert xbuf.dim() == 2
+        b, cin = xbuf.shape
+        desc = Kn.make_conv_desc(b, 1, 1, cin, self.units, (1, 1))
+        x4 = xbuf.view(b, 1, 1, cin)
+        z = plan.empty(b, 1, 1, self.units)
+        wgt = self.kernel.param.view(1, 1, cin, self.units)
+        bias = self.bias.param if self.bias is not None else None
+        relu = self.activation == "relu"
+        plan.emit(lambda: Kn.conv2d_fwd(desc, x4, wgt, bias, z, relu=relu))
+        zv = Value(z.view(b, self.units), needs_grad=True, name=self.name)
+        out = zv
+        if self.activation == "softmax":
+            out = _lower_softmax(plan, zv, self.name + "/softmax")
+
+        def build_backward():
+            if zv.grad is None:
+                return
+            dy2 = zv.grad.buf
+            dy = dy2.view(b, 1, 1, self.units)
+            if relu:
+                plan.emit_bwd(lambda: call("dj_relu_bwd", dy2, self.units, zv.buf, self.units, dy2, self.units, b,
+                                           self.units, 0))
+            if self.bias is not None and self.bias.trainable:
+                _bias_grad(plan, dy2, self.bias)
+            if self.kernel.trainable:
+                dw = self.kernel.grad.view(1, 1, cin, self.units)
+                plan.emit_bwd(lambda: Kn.conv2d_wgrad(desc, x4, dy, dw))
+            if x.needs_grad:
+                dx, beta = plan.grad_of(x)
+                dx4 = dx.view(b, 1, 1, cin)
+                plan.emit_bwd(lambda: Kn.conv2d_dgrad(desc, dy, wgt, dx4, None, bool(beta)))
+
+        # registered before the softmax's builder would be wrong: softmax must run first in backward,
+        # so the Dense builder is registered first (builders run in reverse registration order)
+        plan._bwd_builders.insert(len(plan._bwd_builders) - (1 if self.activation == "softmax" else 0),
+                                  build_backward)
+        return out
+
+
+def _lower_softmax(plan, x, name):
+    xbuf = _materialised(x, name)
+    c = xbuf.shape[-1]
+    rows = xbuf.numel() // c
+    assert xbuf.is_contiguous()
+    y = plan.empty(*xbuf.shape)
+    plan.emit(lambda: call("dj_softmax_fwd", xbuf, y, rows, c))
+    out = Value(y, needs_grad=x.needs_grad, name=name)
+
+    def build_backward():
+        if out.grad is None or not x.needs_grad:
+            return
+        assert out.grad.mask_y is None
+        dp = out.grad.buf
+        assert dp.is_contiguous()
+        dx, beta = plan.grad_of(x)
+        plan.emit_bwd(lambda: call("dj_softmax_bwd", y, dp, c, dx, rows, c, beta))
+
+    plan.on_backward(build_backward)
+    return out
+
+
+# =====================================================================================
+# BatchNormalization / Activation / Add
+# =====================================================================================
+class BatchNormalization(Layer):
+    """keras.layers.BatchNormalization(axis=-1, momentum=0.99, epsilon=1e-3): in training mode batch
+    statistics over (N,H,W); inference uses the moving statistics.  No launch of its own in the
+    forward pass beyond the per-channel finalize: the result is a virtual affine Value."""
+
+    def __init__(self, axis=-1, momentum=0.99, epsilon=1e-3, center=True, scale=True, **kwargs):
+        super(BatchNormalization, self).__init__(**kwargs)
+        if axis not in (-1, 3):
+            raise NotImplementedError("BatchNormalization axis %r (the reference uses bn_axis = 3)" % (axis,))
+        if not (center and scale):
+            raise NotImplementedError("BatchNormalization without gamma/beta")
+        self.axis = axis
+        self.momentum = float(momentum)
+        self.epsilon = float(epsilon)
+
+    def build(self, input_shape):
+        c = input_shape[-1]
+        self.gamma = self.add_weight("gamma", (c,), "ones")
+        self.beta = self.add_weight("beta", (c,), "zeros")
+        self.moving_mean = self.add_weight("moving_mean", (c,), "zeros", trainable=False)
+        self.moving_variance = self.add_weight("moving_variance", (c,), "ones", trainable=False)
+
+    def lower(self, plan, model, ins):
+        x = ins[0]
+        z = _materialised(x, self.name)
+        rows, c, ld = rows_of(z)
+        scale, shift = plan.empty(c), plan.empty(c)
+        gamma, beta = self.gamma.param, self.beta.param
+        mm, mv = self.moving_mean.param, self.moving_variance.param
+        out = Value(z, scale=scale, shift=shift, relu=False, needs_grad=True, name=self.name)
+        out.bn = self
+        if not plan.training:
+            plan.emit(lambda: call("dj_bn_infer_coeffs", gamma, beta, mm, mv, self.epsilon, scale, shift, c))
+            return out
+        mean, invstd = plan.empty(c), plan.empty(c)
+        if x.conv_stats is not None:
+            partial, nrows, conv_bias = x.conv_stats
+        else:
+            nrows = query("dj_reduce_rows", rows)
+            partial, conv_bias = plan.empty(nrows, 2, c), None
+            plan.emit(lambda: call("dj_colstats_partial", z, rows, c, ld, partial))
+        plan.emit(lambda: call("dj_bn_train_finalize", partial, nrows, rows, conv_bias, gamma, beta, self.epsilon,
+                               self.momentum, mm, mv, scale, shift, mean, invstd, c))
+
+        def build_backward():
+            src = out.relu_child if out.relu_child is not None else out
+            if out.relu_child is not None and out.grad is not None:
+                raise NotImplementedError("BatchNormalization output used both with and without its ReLU")
+            if src.grad is None:
+                return
+            dy, mask_y = src.grad.buf, src.grad.mask_y
+            if out.relu_child is not None:
+                assert mask_y is None
+                mode = 2
+            else:
+                mode = 1 if mask_y is not None else 0
+            r2, c2, ld_dy = rows_of(dy)
+            assert (r2, c2) == (rows, c)
+            ld_y = rows_of(mask_y)[2] if mask_y is not None else 0
+            nr = query("dj_reduce_rows", rows)
+            part = plan.empty(nr, 2, c)
+            k0, k1, k2 = plan.empty(c), plan.empty(c), plan.empty(c)
+            dgamma, dbeta = self.gamma.grad, self.beta.grad
+            if dgamma is None:  # frozen layer: scratch
+                dgamma, dbeta = plan.empty(c), plan.empty(c)
+            plan.emit_bwd(lambda: call("dj_bn_bwd_reduce", dy, ld_dy, z, ld, mask_y, ld_y, mean, invstd, scale, shift,
+                                       mode, rows, c, part))
+            plan.emit_bwd(lambda: call("dj_bn_bwd_finalize", part, nr, rows, gamma, mean, invstd, dgamma, dbeta, k0,
+                                       k1, k2, c))
+            if x.needs_grad:
+                dz, beta_acc = plan.grad_of(x)
+                if beta_acc:
+                    raise NotImplementedError("BatchNormalization input with several gradient writers")
+                ld_dz = rows_of(dz)[2]
+                plan.emit_bwd(lambda: call("dj_bn_bwd_apply", dy, ld_dy, z, ld, mask_y, ld_y, scale, shift, mode, k0,
+                                           k1, k2, dz, ld_dz, rows, c))
+
+        plan.on_backward(build_backward)
+        return out
+
+
+class Activation(Layer):
+    def __init__(self, activation, **kwargs):
+        super(Activation, self).__init__(**kwargs)
+        if activation not in ("relu", "softmax", "linear"):
+            raise NotImplementedError("Activation %r" % (activation,))
+        self.activation = activation
+        self.absorbed = False  # set by Add when it fuses this ReLU
+
+    def lower(self, plan, model, ins):
+        x = ins[0]
+        if self.activation == "linear" or self.absorbed:
+            return x
+        if self.activation == "softmax":
+            return _lower_softmax(plan, x, self.name)
+        if x.is_affine and not x.relu:
+            if x.relu_child is not None:
+                raise NotImplementedError("two ReLUs on one BatchNormalization output")
+            v = Value(x.buf, scale=x.scale, shift=x.shift, relu=True, needs_grad=x.needs_grad, name=self.name)
+            x.relu_child = v
+            return v
+        xbuf = _materialised(x, self.name)
+        rows, c, ld = rows_of(xbuf)
+        y = plan.empty(*xbuf.shape)
+        plan.emit(lambda: call("dj_affine_act", xbuf, ld, None, None, None, 0, None, None, y, c, rows, c, 1))
+        out = Value(y, needs_grad=x.needs_grad, name=self.name)
+
+        def build_backward():
+            if out.grad is None or not x.needs_grad:
+                return
+            dy = out.grad.buf
+            dx, beta = plan.grad_of(x)
+            plan.emit_bwd(lambda: call("dj_relu_bwd", dy, rows_of(dy)[2], y, c, dx, rows_of(dx)[2], rows, c, beta))
+
+        plan.on_backward(build_backward)
+        return out
+
+
+class Add(Layer):
+    """keras.layers.Add()([x, shortcut]) followed by Activation('relu')
+    (localisation_part/models/keras_ssd300_dct_j2d_resnet.py:98-99,162-163): one pass that applies
+    the BatchNormalization affines of both branches, adds, and clamps."""
+
+    def compute_output_shape(self, input_shape):
+        return input_shape[0]
+
+    def lower(self, plan, model, ins):
+        a, b = ins
+        if not a.is_affine and b.is_affine:
+            a, b = b, a
+        for v in (a, b):
+            if v.relu or v.pad is not None:
+                raise NotImplementedError("Add over a ReLU-ed virtual tensor")
+        consumers = model.consumers_of(self.outbound[0])
+        relu = len(consumers) == 1 and isinstance(consumers[0], Activation) and consumers[0].activation == "relu"
+        if relu:
+            consumers[0].absorbed = True
+        rows, c, lda = rows_of(a.buf)
+        ldb = rows_of(b.buf)[2]
+        y = plan.empty(*a.buf.shape)
+        abuf, bbuf = a.buf, b.buf
+        plan.emit(lambda: call("dj_affine_act", abuf, lda, a.scale, a.shift, bbuf, ldb, b.scale, b.shift, y, c, rows,
+                               c, int(relu)))
+        out = Value(y, needs_grad=a.needs_grad or b.needs_grad, name=self.name)
+
+        def build_backward():
+            if out.grad is None:
+                return
+            assert out.grad.mask_y is None
+            dy = out.grad.buf
+            for v in (a, b):
+                if not v.needs_grad:
+                    continue
+                if v.is_affine:
+                    plan.set_grad_ref(v, GradRef(dy, y if relu else None))
+                else:
+                    dv, beta = plan.grad_of(v)
+                    if relu:
+                        plan.emit_bwd(lambda dv=dv, beta=beta: call("dj_relu_bwd", dy, c, y, c, dv, rows_of(dv)[2], rows,
+                                                                    c, beta))
+                    else:
+                        plan.emit_bwd(lambda dv=dv, beta=beta: call("dj_copy2d", dy, c, dv, rows_of(dv)[2], rows, c,
+                                                                    beta))
+
+        plan.on_backward(build_backward)
+        return out
+
+
+# =====================================================================================
+# shape / routing layers
+# =====================================================================================
+class Concatenate(Layer):
+    def __init__(self, axis=-1, **kwargs):
+        super(Concatenate, self).__init__(**kwargs)
+        self.axis = axis
+
+    def compute_output_shape(self, input_shape):
+        nd = len(input_shape[0])
+        ax = self.axis % nd
+        out = list(input_shape[0])
+        out[ax] = sum(s[ax] for s in input_shape)
+        for s in input_shape:
+            if [d for i, d in enumerate(s) if i != ax] != [d for i, d in enumerate(out) if i != ax]:
+                raise ValueError("A `Concatenate` layer requires inputs with matching shapes except for the concat "
+                                 "axis. Got inputs shapes: %s" % (input_shape,))
+        return tuple(out)
+
+    def lower(self, plan, model, ins):
+        bufs = [_materialised(v, self.name) for v in ins]
+        nd = bufs[0].dim()
+        ax = self.axis % nd
+        assert ax >= 1
+        outer = 1
+        for d in bufs[0].shape[:ax]:
+            outer *= d
+        inner = [t.numel() // outer for t in bufs]
+        total = sum(inner)
+        shape = list(bufs[0].shape)
+        shape[ax] = sum(t.shape[ax] for t in bufs)
+        y = plan.empty(*shape)
+        yflat = y.view(outer, total)
+        offs, o = [], 0
+        for n in inner:
+            offs.append(o)
+            o += n
+        for t, n, off in zip(bufs, inner, offs):
+            if ax == nd - 1:
+                r, c, ld = rows_of(t)     # may be a channel slice
+                src, lds, rws = t, ld, r
+            else:
+                assert t.is_contiguous()
+                src, lds, rws = t, n, outer
+            dst = yflat[:, off:off + n]
+            plan.emit(lambda src=src, lds=lds, dst=dst, rws=rws, n=n: call("dj_copy2d", src, lds, dst, total, rws, n, 0))
+        out = Value(y, needs_grad=any(v.needs_grad for v in ins), name=self.name)
+
+        def build_backward():
+            if out.grad is None:
+                return
+            assert out.grad.mask_y is None
+            gflat = out.grad.buf.view(outer, total)
+            for v, n, off in zip(ins, inner, offs):
+                if not v.needs_grad:
+                    continue
+                dv, beta = plan.grad_of(v)
+                src = gflat[:, off:off + n]
+                if ax == nd - 1:
+                    r, c, ld = rows_of(dv)
+                    plan.emit_bwd(lambda src=src, dv=dv, ld=ld, r=r, n=n, beta=beta:
+                                  call("dj_copy2d", src, total, dv, ld, r, n, beta))
+                else:
+                    assert dv.is_contiguous()
+                    plan.emit_bwd(lambda src=src, dv=dv, n=n, beta=beta:
+                                  call("dj_copy2d", src, total, dv, n, outer, n, beta))
+
+        plan.on_backward(build_backward)
+        return out
+
+
+class Reshape(Layer):
+    def __init__(self, target_shape, **kwargs):
+        super(Reshape, self).__init__(**kwargs)
+        self.target_shape = tuple(target_shape)
+
+    def compute_output_shape(self, input_shape):
+        known = 1
+        for d in input_shape[1:]:
+            known *= d
+        tgt = list(self.target_shape)
+        if -1 in tgt:
+            i = tgt.index(-1)
+            rest = 1
+            for j, d in enumerate(tgt):
+                if j != i:
+                    rest *= d
+            tgt[i] = known // rest
+        return (input_shape[0],) + tuple(tgt)
+
+    def lower(self, plan, model, ins):
+        x = ins[0]
+        xbuf = _materialised(x, self.name)
+        assert xbuf.is_contiguous()
+        shape = (xbuf.shape[0],) + tuple(self.output_shape[1:])
+        out = Value(xbuf.view(*shape), needs_grad=x.needs_grad, name=self.name)
+        out.alias_of = x
+        out.alias_view = lambda g: g.view(*shape)
+        return out
+
+
+class Flatten(Reshape):
+    def __init__(self, **kwargs):
+        super(Flatten, self).__init__((-1,), **kwargs)
+
+
+class ZeroPadding2D(Layer):
+    """Folded into the following `valid` Conv2D's padding
+    (localisation_part/models/keras_ssd300_dct_j2d_resnet.py:514,1143,1166)."""
+
+    def __init__(self, padding=(1, 1), **kwargs):
+        super(ZeroPadding2D, self).__init__(**kwargs)
+        if isinstance(padding, int):
+            padding = ((padding, padding), (padding, padding))
+        elif isinstance(padding[0], int):
+            padding = ((padding[0], padding[0]), (padding[1], padding[1]))
+        self.padding = (tuple(padding[0]), tuple(padding[1]))
+
+    def compute_output_shape(self, input_shape):
+        b, h, w, c = input_shape
+        return (b, h + sum(self.padding[0]), w + sum(self.padding[1]), c)
+
+    def lower(self, plan, model, ins):
+        x = ins[0]
+        if x.pad is not None:
+            raise NotImplementedError("stacked ZeroPadding2D")
+        out = Value(x.buf, scale=x.scale, shift=x.shift, relu=x.relu, needs_grad=x.needs_grad, name=self.name)
+        out.pad = self.padding
+        out.alias_of = x
+        out.alias_view = lambda g: g
+        return out
+
+
+class MaxPooling2D(Layer):
+    def __init__(self, pool_size=(2, 2), strides=None, padding="valid", **kwargs):
+        super(MaxPooling2D, self).__init__(**kwargs)
+        self.pool_size = _pair(pool_size)
+        self.strides = _pair(strides) if strides is not None else self.pool_size
+        self.padding = padding
+
+    def compute_output_shape(self, input_shape):
+        b, h, w, c = input_shape
+        _, _, oh, ow = Kn.conv_geometry(h, w, self.pool_size, self.strides, self.padding, (1, 1))
+        return (b, oh, ow, c)
+
+    def lower(self, plan, model, ins):
+        if not (self.pool_size == (3, 3) and self.strides == (1, 1) and self.padding == "same"):
+            raise NotImplementedError("MaxPooling2D other than pool5_ssd's (3,3)/1/'same'")
+        x = ins[0]
+        xbuf = _materialised(x, self.name)
+        assert xbuf.is_contiguous()
+        b, h, w, c = xbuf.shape
+        y = plan.empty(b, h, w, c)
+        plan.emit(lambda: call("dj_maxpool3x3s1_fwd", xbuf, y, b, h, w, c))
+        out = Value(y, needs_grad=x.needs_grad, name=self.name)
+
+        def build_backward():
+            if out.grad is None or not x.needs_grad:
+                return
+            dy = out.grad.buf
+            dx, beta = plan.grad_of(x)
+            assert dx.is_contiguous() and dy.is_contiguous()
+            plan.emit_bwd(lambda: call("dj_maxpool3x3s1_bwd", xbuf, dy, dx, b, h, w, c, beta))
+
+        plan.on_backward(build_backward)
+        return out
+
+
+class UpSampling2D(Layer):
+    def __init__(self, size=(2, 2), **kwargs):
+        super(UpSampling2D, self).__init__(**kwargs)
+        self.size = _pair(size)
+        if self.size != (2, 2):
+            raise NotImplementedError("UpSampling2D size %r" % (self.size,))
+
+    def compute_output_shape(self, input_shape):
+        b, h, w, c = input_shape
+        return (b, 2 * h, 2 * w, c)
+
+    def lower(self, plan, model, ins):
+        x = ins[0]
+        xbuf = _materialised(x, self.name)
+        if x.needs_grad:
+            raise NotImplementedError("UpSampling2D gradient (the reference only up-samples model inputs)")
+        b, h, w, c = xbuf.shape
+        y = plan.empty(b, 2 * h, 2 * w, c)
+        plan.emit(lambda: call("dj_upsample2x", xbuf, rows_of(xbuf)[2], y, c, b, h, w, c))
+        return Value(y, needs_grad=False, name=self.name)
+
+
+class GlobalAveragePooling2D(Layer):
+    def compute_output_shape(self, input_shape):
+        return (input_shape[0], input_shape[3])
+
+    def lower(self, plan, model, ins):
+        x = ins[0]
+        xbuf = _materialised(x, self.name)
+        assert xbuf.is_contiguous()
+        b, h, w, c = xbuf.shape
+        y = plan.empty(b, c)
+        plan.emit(lambda: call("dj_global_avg_pool_fwd", xbuf, y, b, h * w, c))
+        out = Value(y, needs_grad=x.needs_grad, name=self.name)
+
+        def build_backward():
+            if out.grad is None or not x.needs_grad:
+                return
+            dy = out.grad.buf
+            dx, beta = plan.grad_of(x)
+            plan.emit_bwd(lambda: call("dj_global_avg_pool_bwd", dy, dx, b, h * w, c, beta))
+
+        plan.on_backward(build_backward)
+        return out
+
+
+class Lambda(Layer):
+    """Only the identity is supported: the reference defines input-normalisation lambdas but never
+    applies them (localisation_part/models/keras_ssd300_dct_j2d_resnet.py:407-435)."""
+
+    def __init__(self, function, output_shape=None, **kwargs):
+        super(Lambda, self).__init__(**kwargs)
+        self.function = function
+
+    def lower(self, plan, model, ins):
+        raise NotImplementedError("Lambda layers have no MI355X lowering")

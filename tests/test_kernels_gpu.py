@@ -1,0 +1,253 @@
+"""GPU parity of the HBM-bound kernels (BatchNormalization, ReLU/Add, L2Normalization, pooling,
+softmax, SSD loss with hard-negative mining, categorical cross-entropy, SGD) against the CPU oracle.
+Tolerance 1e-3 relative (north_star) unless a test states a tighter one."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import keras_ops as ko
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, ref, rel=1e-3, abs_=1e-5):
+    a, ref = a.detach().cpu().double(), ref.detach().cpu().double()
+    return float((a - ref).abs().max()) <= rel * float(ref.abs().max()) + abs_
+
+
+@pytest.fixture()
+def E(cuda):
+    from jpeg_detection_resnet_ssd_amd import engine
+    return engine
+
+
+@pytest.mark.parametrize("shape", [(3, 19, 19, 128), (2, 38, 38, 64), (5, 3, 3, 30), (4, 1, 1, 256)])
+def test_batchnorm_train_forward_backward(shape, cuda, E):
+    g = torch.Generator().manual_seed(11)
+    c = shape[-1]
+    rows = int(np.prod(shape[:-1]))
+    x = torch.randn(shape, generator=g) * 3 + torch.randn(c, generator=g) * 5
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    dy = torch.randn(shape, generator=g)
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yr, mean, var = ko.batch_norm_train(xr, gr, br)
+    out = ko.relu(yr)
+    out.backward(dy.double())
+    mm0, mv0 = torch.zeros(c), torch.ones(c)
+    nm, nv = ko.batch_norm_moving_update(mm0.double(), mv0.double(), mean.detach(), var.detach(), rows)
+
+    xd, gd, bd, dyd = x.to(cuda), gamma.to(cuda), beta.to(cuda), dy.to(cuda)
+    nr = E.query("dj_reduce_rows", rows)
+    part = torch.empty(nr, 2, c, device=cuda)
+    scale, shift, smean, sinv = (torch.empty(c, device=cuda) for _ in range(4))
+    mm, mv = mm0.to(cuda), mv0.to(cuda)
+    E.call("dj_colstats_partial", xd, rows, c, c, part)
+    E.call("dj_bn_train_finalize", part, nr, rows, None, gd, bd, 1e-3, 0.99, mm, mv, scale, shift, smean, sinv, c)
+    y = torch.empty_like(xd)
+    E.call("dj_affine_act", xd, c, scale, shift, None, 0, None, None, y, c, rows, c, 1)
+    torch.cuda.synchronize()
+    assert close(y, out)
+    assert close(mm, nm) and close(mv, nv)
+    # backward with the ReLU mask recomputed from the affine (mask_mode 2)
+    k0, k1, k2, dg, db = (torch.empty(c, device=cuda) for _ in range(5))
+    dz = torch.empty_like(xd)
+    E.call("dj_bn_bwd_reduce", dyd, c, xd, c, None, 0, smean, sinv, scale, shift, 2, rows, c, part)
+    E.call("dj_bn_bwd_finalize", part, nr, rows, gd, smean, sinv, dg, db, k0, k1, k2, c)
+    E.call("dj_bn_bwd_apply", dyd, c, xd, c, None, 0, scale, shift, 2, k0, k1, k2, dz, c, rows, c)
+    torch.cuda.synchronize()
+    assert close(dg, gr.grad) and close(db, br.grad)
+    assert close(dz, xr.grad, rel=2e-3)
+    # mask_mode 1 (mask from the materialised output) gives the same result
+    dz1 = torch.empty_like(xd)
+    E.call("dj_bn_bwd_reduce", dyd, c, xd, c, y, c, smean, sinv, None, None, 1, rows, c, part)
+    E.call("dj_bn_bwd_finalize", part, nr, rows, gd, smean, sinv, dg, db, k0, k1, k2, c)
+    E.call("dj_bn_bwd_apply", dyd, c, xd, c, y, c, None, None, 1, k0, k1, k2, dz1, c, rows, c)
+    torch.cuda.synchronize()
+    assert close(dz1, xr.grad, rel=2e-3)
+
+
+def test_add_relu_and_relu_bwd_and_copy(cuda, E):
+    g = torch.Generator().manual_seed(5)
+    rows, c = 700, 96
+    a, b = torch.randn(rows, c, generator=g), torch.randn(rows, c, generator=g)
+    sa, ta, sb, tb = (torch.randn(c, generator=g) for _ in range(4))
+    ref = ko.relu(a * sa + ta + b * sb + tb)
+    y = torch.empty(rows, c, device=cuda)
+    E.call("dj_affine_act", a.to(cuda), c, sa.to(cuda), ta.to(cuda), b.to(cuda), c, sb.to(cuda), tb.to(cuda), y, c,
+           rows, c, 1)
+    torch.cuda.synchronize()
+    assert close(y, ref, rel=1e-5)
+    dy = torch.randn(rows, c, generator=g)
+    dx = torch.ones(rows, c, device=cuda)
+    E.call("dj_relu_bwd", dy.to(cuda), c, y, c, dx, c, rows, c, 1)
+    torch.cuda.synchronize()
+    assert close(dx, 1.0 + dy * (ref > 0), rel=1e-6)
+    # strided copy into a channel slice, then accumulate
+    dst = torch.zeros(rows, 200, device=cuda)
+    E.call("dj_copy2d", a.to(cuda), c, dst[:, 50:50 + c], 200, rows, c, 0)
+    E.call("dj_copy2d", a.to(cuda), c, dst[:, 50:50 + c], 200, rows, c, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(dst[:, 50:50 + c].cpu(), 2 * a) and float(dst[:, :50].abs().max()) == 0
+
+
+def test_upsample_and_gap(cuda, E):
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 19, 19, 128, generator=g)
+    y = torch.zeros(2, 38, 38, 192, device=cuda)
+    E.call("dj_upsample2x", x.to(cuda), 128, y[..., 64:], 192, 2, 19, 19, 128)
+    torch.cuda.synchronize()
+    assert torch.equal(y[..., 64:].cpu(), ko.upsampling_nearest_2x(x))
+    p = torch.empty(2, 128, device=cuda)
+    E.call("dj_global_avg_pool_fwd", x.to(cuda), p, 2, 361, 128)
+    torch.cuda.synchronize()
+    assert close(p, ko.global_average_pooling(x), rel=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 38, 38, 384), (3, 10, 10, 1024), (2, 38, 38, 64)])
+def test_l2norm(shape, cuda, E):
+    g = torch.Generator().manual_seed(8)
+    c = shape[-1]
+    rows = int(np.prod(shape[:-1]))
+    x = torch.randn(shape, generator=g) * 4
+    x[0, 0, 0] = 0.0  # a zero pixel hits the 1e-12 clamp
+    gamma = torch.rand(c, generator=g) * 5 + 18
+    dy = torch.randn(shape, generator=g)
+    xr, gr = x.double().requires_grad_(True), gamma.double().requires_grad_(True)
+    yr = ko.l2_normalization(xr, gr)
+    yr.backward(dy.double())
+    xd, gd, dyd = x.to(cuda), gamma.to(cuda), dy.to(cuda)
+    y, rn = torch.empty_like(xd), torch.empty(rows, device=cuda)
+    E.call("dj_l2norm_fwd", xd, c, gd, y, c, rn, rows, c)
+    nr = E.query("dj_reduce_rows", rows)
+    part = torch.empty(nr, 2, c, device=cuda)
+    dx, dg = torch.empty_like(xd), torch.empty(c, device=cuda)
+    E.call("dj_l2norm_bwd", dyd, c, xd, c, gd, rn, dx, c, part, rows, c, 0)
+    E.call("dj_colreduce_finalize", part, nr, c, 0, dg, 0)
+    torch.cuda.synchronize()
+    assert close(y, yr)
+    mask = torch.ones(shape, dtype=torch.bool)
+    mask[0, 0, 0] = False  # autograd of rsqrt(clamp) at the clamp differs from the constant-norm gradient
+    assert close(dx.cpu()[mask], xr.grad[mask])
+    assert close(dg, gr.grad)
+
+
+@pytest.mark.parametrize("hw", [5, 10])
+def test_maxpool(hw, cuda, E):
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(3, hw, hw, 256, generator=g)
+    dy = torch.randn(3, hw, hw, 256, generator=g)
+    xr = x.double().requires_grad_(True)
+    yr = ko.max_pool_3x3_s1_same(xr)
+    yr.backward(dy.double())
+    y, dx = torch.empty(x.shape, device=cuda), torch.empty(x.shape, device=cuda)
+    E.call("dj_maxpool3x3s1_fwd", x.to(cuda), y, 3, hw, hw, 256)
+    E.call("dj_maxpool3x3s1_bwd", x.to(cuda), dy.to(cuda), dx, 3, hw, hw, 256, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu().double(), yr.detach())
+    assert close(dx, xr.grad, rel=1e-5)
+
+
+@pytest.mark.parametrize("rows,c", [(5000, 21), (64, 1000)])
+def test_softmax(rows, c, cuda, E):
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(rows, c, generator=g) * 4
+    dp = torch.randn(rows, c, generator=g)
+    xr = x.double().requires_grad_(True)
+    pr = ko.softmax(xr)
+    pr.backward(dp.double())
+    p, dx = torch.empty(rows, c, device=cuda), torch.empty(rows, c, device=cuda)
+    E.call("dj_softmax_fwd", x.to(cuda), p, rows, c)
+    E.call("dj_softmax_bwd", p, dp.to(cuda), c, dx, rows, c, 0)
+    torch.cuda.synchronize()
+    assert close(p, pr) and close(dx, xr.grad)
+
+
+def _ssd_case(batch, nbox, seed, pos_frac):
+    g = torch.Generator().manual_seed(seed)
+    n_cls = 21
+    logits = torch.randn(batch, nbox, n_cls, generator=g) * 2
+    loc = torch.randn(batch, nbox, 4, generator=g) * 1.5
+    anchors = torch.rand(batch, nbox, 8, generator=g)
+    y_true = torch.zeros(batch, nbox, 33)
+    u = torch.rand(batch, nbox, generator=g)
+    cls = torch.randint(1, n_cls, (batch, nbox), generator=g)
+    pos = u < pos_frac
+    neutral = (u >= pos_frac) & (u < pos_frac + 0.02)
+    neg = ~pos & ~neutral
+    y_true[..., 0][neg] = 1.0
+    y_true.view(-1, 33)[pos.view(-1).nonzero().squeeze(1), cls.view(-1)[pos.view(-1)]] = 1.0
+    y_true[..., 21:25] = torch.randn(batch, nbox, 4, generator=g)
+    y_true[..., 25:] = anchors
+    return logits, loc, anchors, y_true
+
+
+@pytest.mark.parametrize("batch,nbox,pos_frac", [(4, 8732, 0.004), (2, 500, 0.0), (3, 700, 0.4), (32, 8732, 0.003)])
+def test_ssd_loss(batch, nbox, pos_frac, cuda, E):
+    logits, loc, anchors, y_true = _ssd_case(batch, nbox, 21, pos_frac)
+    lr = logits.double().requires_grad_(True)
+    locr = loc.double().requires_grad_(True)
+    ypr = torch.cat([ko.softmax(lr), locr, anchors.double()], dim=2)
+    ypr.retain_grad()
+    vec, parts = ko.ssd_loss(y_true.double(), ypr, return_parts=True)
+    loss = vec.mean()
+    loss.backward()
+
+    yp = torch.cat([torch.softmax(logits, -1), loc, anchors], dim=2).to(cuda).contiguous()
+    yt = y_true.to(cuda)
+    n = batch * nbox
+    ws = torch.empty(E.query("dj_ssd_loss_workspace_floats", n), device=cuda)
+    out = torch.zeros(8, device=cuda)
+    d = torch.full((batch, nbox, 33), float("nan"), device=cuda)
+    E.call("dj_ssd_loss_fwd", yt, yp, n, 21, 3, 0, 1.0, ws, out)
+    E.call("dj_ssd_loss_bwd", yt, yp, n, 21, 1.0, 1.0, ws, out, d)
+    torch.cuda.synchronize()
+    o = out.cpu()
+    assert abs(float(o[0]) - float(loss)) <= 1e-3 * abs(float(loss)) + 1e-6
+    assert int(o[1]) == int(parts["n_positive"]) and int(o[2]) == parts["n_keep"]
+    keep = ws[4 * n:5 * n].cpu().view(batch, nbox)
+    assert int(keep.sum()) == parts["n_keep"]
+    # the kept set may differ from torch.topk only among exactly tied losses
+    kr = parts["keep"]
+    diff = (keep.double() != kr)
+    if diff.any():
+        negl = (parts["cls"] * parts["negatives"]).detach()
+        assert negl[diff].unique().numel() == 1
+    assert close(d, ypr.grad, rel=1e-3, abs_=1e-7)
+
+
+def test_categorical_crossentropy(cuda, E):
+    g = torch.Generator().manual_seed(12)
+    rows, c = 64, 1000
+    logits = torch.randn(rows, c, generator=g) * 3
+    y = torch.zeros(rows, c)
+    y[torch.arange(rows), torch.randint(0, c, (rows,), generator=g)] = 1.0
+    lr = logits.double().requires_grad_(True)
+    pr = ko.softmax(lr)
+    pr.retain_grad()
+    loss = ko.categorical_crossentropy(y.double(), pr).mean()
+    loss.backward()
+    p = torch.softmax(logits, -1).to(cuda)
+    lrows, dp, out = torch.empty(rows, device=cuda), torch.empty(rows, c, device=cuda), torch.zeros(8, device=cuda)
+    E.call("dj_categorical_crossentropy", y.to(cuda), p, rows, c, 1.0, lrows, dp, out)
+    dx = torch.empty(rows, c, device=cuda)
+    E.call("dj_softmax_bwd", p, dp, c, dx, rows, c, 0)
+    torch.cuda.synchronize()
+    assert abs(float(out[0]) - float(loss)) <= 1e-4 * float(loss)
+    assert close(dx, lr.grad)
+
+
+@pytest.mark.parametrize("nesterov", [False, True])
+def test_sgd_keras_formula(nesterov, cuda, E):
+    g = torch.Generator().manual_seed(13)
+    n = 100003
+    p, gr, v = (torch.randn(n, generator=g) for _ in range(3))
+    lr_t = 0.1 / (1 + 1e-4 * 7)
+    g_eff = gr.double() * 0.125 + 2 * 5e-4 * p.double()
+    pn, vn = ko.sgd_keras_step(p.double(), g_eff, v.double(), 0.1, 0.9, 1e-4, 7, nesterov)
+    pd, gd, vd = p.to(cuda), gr.to(cuda), v.to(cuda)
+    ss = torch.zeros(1, device=cuda)
+    E.call("dj_sgd_momentum_update", pd, gd, vd, n, lr_t, 0.9, int(nesterov), 5e-4, 0.125, ss)
+    torch.cuda.synchronize()
+    assert close(pd, pn, rel=1e-6) and close(vd, vn, rel=1e-6)
+    assert abs(float(ss) - float((p.double() ** 2).sum())) <= 1e-4 * float((p.double() ** 2).sum())
