@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""Training-throughput benchmark of the hot path: images/sec of ResNet50-DCT SSD300 training steps
+(forward + multibox loss + backward + Keras-SGD update, data-parallel gradient all-reduce when N > 1).
+
+    python bench.py --gpus N --steps K --warmup W [--archi deconv|ssd_custom|up_sampling] [--batch 32]
+
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`,
+one rank per GPU over RCCL.  Inputs (synthetic JPEG-DCT coefficients + encoder-made targets) are resident
+in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+
+
+def conv_flops(desc):
+    return 2.0 * desc.batch * desc.out_h * desc.out_w * desc.out_c * desc.kernel_h * desc.kernel_w * desc.in_c
+
+
+def measure_conv_kernels(model, plan):
+    """One extra (untimed-for-throughput) step with every implicit-GEMM launch bracketed by HIP events
+    on the launch stream: -> dict(total_ms, flop, launches)."""
+    from jpeg_detection_resnet_ssd_amd import kernels as Kn
+    records = []
+    originals = {}
+
+    def wrap(name):
+        f = getattr(Kn, name)
+        originals[name] = f
+
+        def timed(desc, *a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = f(desc, *a, **kw)
+            e1.record()
+            records.append((e0, e1, conv_flops(desc)))
+            return r
+        setattr(Kn, name, timed)
+
+    for n in ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad"):
+        wrap(n)
+    try:
+        model.run_train_step(plan)
+        torch.cuda.synchronize()
+    finally:
+        for n, f in originals.items():
+            setattr(Kn, n, f)
+    total_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in records)
+    flop = sum(fl for _, _, fl in records)
+    return dict(total_ms=total_ms, flop=flop, launches=len(records))
+
+
+def available_cores():
+    """CPU cores this process may really use: affinity mask and cgroup quota, not the host's core count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(archi, batch, budget_s=25.0):
+    """The oracle (CPU restatement of the reference's Keras path, fp32) timed on this host's cores on a
+    bounded sample: whole training steps at a small batch until `budget_s` seconds are used."""
+    from jpeg_detection_resnet_ssd_amd import workloads
+    from oracle import ssd_resnet_dct as oracle
+    cores = min(available_cores(), 32)
+    torch.set_num_threads(cores)
+    model, sizes = workloads.build_ssd(archi, compile_model=False)
+    x, y = workloads.synthetic_batch(archi, sizes, batch, fast=True)
+    w = {s.key: torch.as_tensor(s.initializer(s.shape), dtype=torch.float32) for s in model.weight_specs}
+    xs = [torch.from_numpy(a) for a in x]
+    yt = torch.from_numpy(y)
+    times, t_start = [], time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        oracle.ssd_training_step(w, xs, yt, archi)
+        times.append(time.perf_counter() - t0)
+        print("cpu_baseline: step %d took %.2f s on %d threads" % (len(times), times[-1], cores), file=sys.stderr,
+              flush=True)
+        if time.perf_counter() - t_start > budget_s or len(times) >= 6:
+            break
+    use = times[1:] if len(times) > 1 else times   # first step pays one-time allocator / thread-pool start-up
+    med = float(np.median(use))
+    return {"value": batch / med, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "%d oracle training steps (PyTorch-CPU fp32 restatement of the reference's Keras graph, %s SSD300) "
+                      "at batch %d; median step %.2f s" % (len(use), archi, batch, med)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--archi", default="deconv", choices=["deconv", "ssd_custom", "up_sampling"])
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU (the reference trainer's batch_size)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of CPU work for the cpu_baseline sample")
+    args = ap.parse_args()
+
+    from jpeg_detection_resnet_ssd_amd import dist as djdist
+    from jpeg_detection_resnet_ssd_amd import workloads
+    rank, world, local = djdist.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the compute path has no CPU fallback")
+    torch.cuda.set_device(local)
+
+    model, sizes = workloads.build_ssd(args.archi)
+    model._ensure_params()
+    dp = None
+    if world > 1:
+        dp = djdist.DataParallel(model)
+        dp.broadcast_weights(0)
+    # rank r draws its own shard of the global batch (data seed 1234 + r)
+    x, y = workloads.synthetic_batch(args.archi, sizes, args.batch, seed=1234 + rank, fast=True)
+    plan = model._plan(args.batch, True, True)
+    model._upload(plan, x, y)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        model.run_train_step(plan)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.run_train_step(plan)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = model._loss_value(plan)
+    print("rank %d: %d steps in %.3f s, last loss %.4f" % (rank, args.steps, elapsed, loss), file=sys.stderr, flush=True)
+
+    if rank != 0:
+        return
+    images = world * args.batch * args.steps
+    value = images / elapsed
+    gflop = workloads.TRAIN_GFLOP_PER_IMAGE[args.archi]
+    per_gpu_tflops = value * gflop / 1e3 / world
+    out = {
+        "metric": "images/sec (train) ResNet50-DCT-SSD300",
+        "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "SSD300 ResNet50-DCT '%s' archi, %d images/GPU, 300x300 JPEG-DCT inputs "
+                               "(Y 38x38x64 + chroma 19x19), fwd+loss+bwd+SGD(+RCCL all-reduce)" % (args.archi, args.batch),
+                   "archi": args.archi, "global_batch": world * args.batch, "parallelism": "dp%d" % world,
+                   "train_gflop_per_image": gflop, "last_loss": loss},
+    }
+    roof = {"bound": "mfma", "achieved": per_gpu_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": per_gpu_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            "note": "whole-step algorithmic conv FLOPs (SURVEY 8(d) table) / step time, per GPU"}
+    if world == 1:
+        k = measure_conv_kernels(model, plan)
+        ktf = k["flop"] / (k["total_ms"] * 1e-3) / 1e12
+        roof["dominant_kernel"] = {"name": "dj_igemm_kernel (conv fwd/dgrad/wgrad)", "launches_per_step": k["launches"],
+                                   "avg_launch_us": 1e3 * k["total_ms"] / k["launches"],
+                                   "ms_per_step": k["total_ms"], "achieved": ktf, "frac": ktf / PEAK_FP32_MFMA_TFLOPS,
+                                   "algorithmic_gflop_per_step": k["flop"] / 1e9}
+    out["roofline"] = roof
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.archi, args.cpu_batch, args.cpu_budget)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

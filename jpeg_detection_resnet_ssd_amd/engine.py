@@ -87,7 +87,8 @@ class Plan(object):
         self.y_true = None
         self.loss_out = None   # device float[5]
         self.bytes_allocated = 0
-        self.hooks_after_backward = []  # e.g. data-parallel gradient exchange
+        self.hooks_after_backward = []
+        self.grad_ready = {}   # weight key -> index in self.bwd after which its gradient is final
 
     # ---- allocation -------------------------------------------------------------
     def empty(self, *shape):
@@ -106,6 +107,10 @@ class Plan(object):
 
     def emit_bwd(self, fn):
         self.bwd.append(fn)
+
+    def note_grad(self, spec):
+        """Record that every launch writing `spec.grad` has been emitted (data-parallel bucketing)."""
+        self.grad_ready[spec.key] = len(self.bwd)
 
     def on_backward(self, builder):
         """Register a function that appends this op's backward launches; builders run in reverse

@@ -203,6 +203,7 @@ def _bias_grad(plan, dy, spec):
     partial = plan.empty(nr, 2, c)
     plan.emit_bwd(lambda: call("dj_colsum_partial", dy, rows, c, ld, partial))
     plan.emit_bwd(lambda: call("dj_colreduce_finalize", partial, nr, c, 0, spec.grad, 0))
+    plan.note_grad(spec)
 
 
 # =====================================================================================
@@ -281,6 +282,7 @@ class Conv2D(Layer):
             if self.kernel.trainable:
                 dw = self.kernel.grad
                 plan.emit_bwd(lambda: Kn.conv2d_wgrad(desc, xbuf, dy, dw, pro[0], pro[1], pro[2]))
+                plan.note_grad(self.kernel)
             if x.needs_grad:
                 dx, beta = plan.grad_of(x)
                 plan.emit_bwd(lambda: Kn.conv2d_dgrad(desc, dy, wgt, dx, None, bool(beta)))
@@ -343,6 +345,7 @@ class Conv2DTranspose(Layer):
             if self.kernel.trainable:
                 dw = self.kernel.grad
                 plan.emit_bwd(lambda: Kn.conv2d_wgrad(desc, dy, xbuf, dw))
+                plan.note_grad(self.kernel)
             if x.needs_grad:
                 dx, beta = plan.grad_of(x)
                 if beta:
@@ -407,6 +410,7 @@ class Dense(Layer):
             if self.kernel.trainable:
                 dw = self.kernel.grad.view(1, 1, cin, self.units)
                 plan.emit_bwd(lambda: Kn.conv2d_wgrad(desc, x4, dy, dw))
+                plan.note_grad(self.kernel)
             if x.needs_grad:
                 dx, beta = plan.grad_of(x)
                 dx4 = dx.view(b, 1, 1, cin)
@@ -513,6 +517,8 @@ class BatchNormalization(Layer):
                                        mode, rows, c, part))
             plan.emit_bwd(lambda: call("dj_bn_bwd_finalize", part, nr, rows, gamma, mean, invstd, dgamma, dbeta, k0,
                                        k1, k2, c))
+            plan.note_grad(self.gamma)
+            plan.note_grad(self.beta)
             if x.needs_grad:
                 dz, beta_acc = plan.grad_of(x)
                 if beta_acc:

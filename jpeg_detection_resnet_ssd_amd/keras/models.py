@@ -260,6 +260,8 @@ class Model(object):
             plan.on_backward(seed_gradient)
         if training:
             plan.build_backward()
+            if self.dist is not None and with_loss:
+                self.dist.attach(plan)
         self._plans[key] = plan
         return plan
 

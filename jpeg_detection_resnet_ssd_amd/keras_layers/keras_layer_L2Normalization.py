@@ -58,6 +58,7 @@ class L2Normalization(Layer):
             if partial is not None:
                 dg = self.gamma.grad
                 plan.emit_bwd(lambda: call("dj_colreduce_finalize", partial, nr, c, 0, dg, 0))
+                plan.note_grad(self.gamma)
 
         plan.on_backward(build_backward)
         return out

@@ -273,5 +273,5 @@ def ssd_training_step(weights, inputs, y_true, archi, lr=0.001, momentum=0.9, de
         else:
             new_w[k] = v.detach()
     new_w.update(net.new_state)
-    return dict(loss=float(loss), data_loss=float(data_loss), reg_loss=float(reg), y_pred=y_pred.detach(),
+    return dict(loss=float(loss.detach()), data_loss=float(data_loss.detach()), reg_loss=float(reg.detach()), y_pred=y_pred.detach(),
                 grads=grads, new_weights=new_w, new_velocities=new_v, net=net)
