@@ -313,8 +313,15 @@ extern "C" int dj_conv2d_nhwc_wgrad(const dj_conv2d_desc* d, const float* x, con
   p.vecA = (d->in_c % 4 == 0) && (d->ld_x % 4 == 0) && aligned16(x) &&
            (!pro_scale || (aligned16(pro_scale) && aligned16(pro_shift)));
   p.vecB = (d->out_c % 4 == 0) && (d->ld_y % 4 == 0) && aligned16(dy);
+  // tile by the (taps*Cin) x Cout extent only -- the pixel reduction is split over blockIdx.y to fill the chip
   int splits = 1;
-  int cfg = choose_cfg(p.M, p.N, p.K, false, &splits);
+  int cfg;
+  if (p.N > 96 && (long)dj_cdiv(p.N, 128) * 128 <= (long)dj_cdiv(p.N, 64) * 64)
+    cfg = (p.M >= 128) ? CFG_128x128 : CFG_64x64;
+  else if (p.N > 32)
+    cfg = (p.M >= 128) ? CFG_128x64 : CFG_64x64;
+  else
+    cfg = CFG_128x32;
   long t = (long)dj_cdiv(p.M, kCfgs[cfg].bm) * dj_cdiv(p.N, kCfgs[cfg].bn);
   long want = (768 + t - 1) / t;
   long maxs = p.K / 128;

@@ -115,6 +115,36 @@ static int launch_colreduce(F f, long rows, int C, float* partial, hipStream_t s
   return DJ_OK;
 }
 
+
+// Column sums of the two partial slots for 32 channels per block: 1024 threads = 32 channels x 32 row
+// lanes, coalesced 128-byte reads, double accumulation.  Valid in threads with ty == 0 (c < C).
+#define DJ_FIN_THREADS 1024
+__device__ __forceinline__ void dj_partial_sums(const float* partial, int nrows, int C, int which_mask, double& s0,
+                                                double& s1) {
+  __shared__ double red0[32][33];
+  __shared__ double red1[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + tx;
+  double a = 0.0, b = 0.0;
+  if (c < C) {
+    for (int r = ty; r < nrows; r += 32) {
+      if (which_mask & 1) a += (double)partial[((size_t)r * 2 + 0) * C + c];
+      if (which_mask & 2) b += (double)partial[((size_t)r * 2 + 1) * C + c];
+    }
+  }
+  red0[ty][tx] = a;
+  red1[ty][tx] = b;
+  __syncthreads();
+  if (ty == 0) {
+    for (int j = 1; j < 32; ++j) {
+      a += red0[j][tx];
+      b += red1[j][tx];
+    }
+  }
+  s0 = a;
+  s1 = b;
+}
+
 extern "C" int dj_reduce_rows(long rows) { return dj_cdiv(rows, DJ_RB); }
 
 extern "C" int dj_colstats_partial(const float* x, long rows, int C, int ld, float* partial, void* stream) {
@@ -130,13 +160,13 @@ extern "C" int dj_colsum_partial(const float* dy, long rows, int C, int ld, floa
 }
 
 // out[c] (+)= sum_r partial[r][which][c]
-__global__ void dj_colreduce_finalize_kernel(const float* partial, int nrows, int C, int which, float* out,
-                                             int beta) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0;
-  for (int r = 0; r < nrows; ++r) s += (double)partial[((size_t)r * 2 + which) * C + c];
-  float v = (float)s;
+__global__ __launch_bounds__(DJ_FIN_THREADS) void dj_colreduce_finalize_kernel(const float* partial, int nrows, int C,
+                                                                               int which, float* out, int beta) {
+  double s0, s1;
+  dj_partial_sums(partial, nrows, C, which == 0 ? 1 : 2, s0, s1);
+  int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  if ((threadIdx.x >> 5) != 0 || c >= C) return;
+  float v = (float)(which == 0 ? s0 : s1);
   if (beta) v += out[c];
   out[c] = v;
 }
@@ -144,8 +174,8 @@ __global__ void dj_colreduce_finalize_kernel(const float* partial, int nrows, in
 extern "C" int dj_colreduce_finalize(const float* partial, int nrows, int C, int which, float* out, int beta,
                                      void* stream) {
   DJ_CHECK_ARG(partial && out && nrows > 0 && C > 0 && (which == 0 || which == 1), "colreduce_finalize: bad arguments");
-  hipLaunchKernelGGL(dj_colreduce_finalize_kernel, dim3(dj_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, partial,
-                     nrows, C, which, out, beta);
+  hipLaunchKernelGGL(dj_colreduce_finalize_kernel, dim3(dj_cdiv(C, 32)), dim3(DJ_FIN_THREADS), 0, (hipStream_t)stream,
+                     partial, nrows, C, which, out, beta);
   DJ_CHECK_LAUNCH("dj_colreduce_finalize");
   return DJ_OK;
 }
@@ -153,17 +183,14 @@ extern "C" int dj_colreduce_finalize(const float* partial, int nrows, int C, int
 // ---------------------------------------------------------------------------------
 // BatchNormalization, training mode: finalize statistics -> (scale, shift)
 // ---------------------------------------------------------------------------------
-__global__ void dj_bn_train_finalize_kernel(const float* partial, int nrows, double count, const float* conv_bias,
+__global__ __launch_bounds__(DJ_FIN_THREADS) void dj_bn_train_finalize_kernel(const float* partial, int nrows, double count, const float* conv_bias,
                                             const float* gamma, const float* beta, float eps, float momentum,
                                             float* moving_mean, float* moving_var, float* scale, float* shift,
                                             float* save_mean, float* save_invstd, int C) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int r = 0; r < nrows; ++r) {
-    s += (double)partial[((size_t)r * 2 + 0) * C + c];
-    q += (double)partial[((size_t)r * 2 + 1) * C + c];
-  }
+  double s, q;
+  dj_partial_sums(partial, nrows, C, 3, s, q);
+  int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  if ((threadIdx.x >> 5) != 0 || c >= C) return;
   double m = s / count;
   double var = q / count - m * m;
   if (var < 0.0) var = 0.0;
@@ -189,7 +216,7 @@ extern "C" int dj_bn_train_finalize(const float* partial, int nrows, long count,
   DJ_CHECK_ARG(partial && gamma && beta && scale && shift && save_mean && save_invstd, "bn_train_finalize: null");
   DJ_CHECK_ARG(nrows > 0 && count > 0 && C > 0, "bn_train_finalize: bad sizes");
   DJ_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "bn_train_finalize: moving stats come together");
-  hipLaunchKernelGGL(dj_bn_train_finalize_kernel, dim3(dj_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, partial,
+  hipLaunchKernelGGL(dj_bn_train_finalize_kernel, dim3(dj_cdiv(C, 32)), dim3(DJ_FIN_THREADS), 0, (hipStream_t)stream, partial,
                      nrows, (double)count, conv_bias, gamma, beta, eps, momentum, moving_mean, moving_var, scale,
                      shift, save_mean, save_invstd, C);
   DJ_CHECK_LAUNCH("dj_bn_train_finalize");
@@ -292,16 +319,13 @@ extern "C" int dj_bn_bwd_reduce(const float* dy, int ld_dy, const float* z, int 
 }
 
 // dgamma, dbeta and the coefficients of dz = k0*dy_masked + k1*z + k2
-__global__ void dj_bn_bwd_finalize_kernel(const float* partial, int nrows, double count, const float* gamma,
+__global__ __launch_bounds__(DJ_FIN_THREADS) void dj_bn_bwd_finalize_kernel(const float* partial, int nrows, double count, const float* gamma,
                                           const float* mean, const float* invstd, float* dgamma, float* dbeta,
                                           float* k0, float* k1, float* k2, int C) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double sb = 0.0, sg = 0.0;
-  for (int r = 0; r < nrows; ++r) {
-    sb += (double)partial[((size_t)r * 2 + 0) * C + c];
-    sg += (double)partial[((size_t)r * 2 + 1) * C + c];
-  }
+  double sb, sg;
+  dj_partial_sums(partial, nrows, C, 3, sb, sg);
+  int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  if ((threadIdx.x >> 5) != 0 || c >= C) return;
   dbeta[c] = (float)sb;
   dgamma[c] = (float)sg;
   double is = (double)invstd[c], sc = (double)gamma[c] * is;
@@ -316,7 +340,7 @@ extern "C" int dj_bn_bwd_finalize(const float* partial, int nrows, long count, c
                                   int C, void* stream) {
   DJ_CHECK_ARG(partial && gamma && mean && invstd && dgamma && dbeta && k0 && k1 && k2, "bn_bwd_finalize: null");
   DJ_CHECK_ARG(nrows > 0 && count > 0 && C > 0, "bn_bwd_finalize: bad sizes");
-  hipLaunchKernelGGL(dj_bn_bwd_finalize_kernel, dim3(dj_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, partial,
+  hipLaunchKernelGGL(dj_bn_bwd_finalize_kernel, dim3(dj_cdiv(C, 32)), dim3(DJ_FIN_THREADS), 0, (hipStream_t)stream, partial,
                      nrows, (double)count, gamma, mean, invstd, dgamma, dbeta, k0, k1, k2, C);
   DJ_CHECK_LAUNCH("dj_bn_bwd_finalize");
   return DJ_OK;
