@@ -64,6 +64,10 @@ int dj_conv2d_nhwc_fwd(const dj_conv2d_desc* d, const float* x, const float* w, 
 int dj_conv2d_nhwc_dgrad(const dj_conv2d_desc* d, const float* dy, const float* w, const float* bias,
                          float* dx, int beta, void* stream);
 
+/* Debug/test switch: 0 forces the generic (branchy, any-shape) implicit-GEMM kernel, 1 (default) lets the
+ * launcher pick the branch-free buffer-load kernel whenever its alignment preconditions hold. */
+void dj_set_fast_path(int enable);
+
 /* dw = sum over pixels pro(x)^T dy  (TF Conv2DBackpropFilter).  dw is HWIO, overwritten. */
 int dj_conv2d_nhwc_wgrad(const dj_conv2d_desc* d, const float* x, const float* dy, float* dw,
                          const float* pro_scale, const float* pro_shift, int pro_relu, void* stream);

@@ -49,6 +49,7 @@ SIGNATURES = {
     "dj_conv2d_nhwc_fwd": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, FP, c_int, c_int, FP, c_void_p]),
     "dj_conv2d_nhwc_dgrad": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, c_int, c_void_p]),
     "dj_conv2d_nhwc_wgrad": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, c_int, c_void_p]),
+    "dj_set_fast_path": (None, [c_int]),
     "dj_reduce_rows": (c_int, [c_long]),
     "dj_colstats_partial": (c_int, [FP, c_long, c_int, c_int, FP, c_void_p]),
     "dj_colsum_partial": (c_int, [FP, c_long, c_int, c_int, FP, c_void_p]),

@@ -1,6 +1,7 @@
 // Host launchers of the implicit-GEMM convolution (see dj_igemm.h for the kernel).
 #include "../../include/dj_hip.h"
 #include "dj_igemm.h"
+#include "dj_igemm_fast.h"
 #include <string.h>
 
 static thread_local char g_err[512] = "";
@@ -22,34 +23,60 @@ struct TileCfg {
 static const TileCfg kCfgs[] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}};
 enum { CFG_128x128 = 0, CFG_128x64, CFG_64x64, CFG_128x32, N_CFG };
 
-template <int BM, int BN, int WM, int WN, int AM, int BMD>
-static int launch_one(const DjIgemmParams& p, int splits, hipStream_t s) {
-  using Cfg = DjIgemmCfg<BM, BN, WM, WN, AM, BMD>;
-  auto kern = dj_igemm_kernel<BM, BN, WM, WN, AM, BMD>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       Cfg::SMEM_BYTES);
+template <typename KernT>
+static int launch_kernel(KernT kern, int smem_bytes, int bm, int bn, const DjIgemmParams& p, int splits, hipStream_t s,
+                         bool* attr_done) {
+  if (!*attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     if (e != hipSuccess) {
-      dj_set_error("hipFuncSetAttribute(%d B LDS): %s", Cfg::SMEM_BYTES, hipGetErrorString(e));
+      dj_set_error("hipFuncSetAttribute(%d B LDS): %s", smem_bytes, hipGetErrorString(e));
       return DJ_ERR_HIP;
     }
-    attr_done = true;
+    *attr_done = true;
   }
-  int tiles_m = dj_cdiv(p.M, BM), tiles_n = dj_cdiv(p.N, BN);
+  int tiles_m = dj_cdiv(p.M, bm), tiles_n = dj_cdiv(p.N, bn);
   dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)splits);
-  hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::SMEM_BYTES, s, p);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem_bytes, s, p);
   DJ_CHECK_LAUNCH("dj_igemm_kernel");
   return DJ_OK;
 }
 
+// fast = 0: generic kernel; 1: branch-free kernel; 2: branch-free kernel with the affine prologue
+template <int BM, int BN, int WM, int WN, int AM, int BMD>
+static int launch_one(const DjIgemmParams& p, int splits, hipStream_t s, int fast) {
+  using Cfg = DjIgemmCfg<BM, BN, WM, WN, AM, BMD>;
+  static bool done[3] = {false, false, false};
+  if (fast == 1)
+    return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 0>, Cfg::SMEM_BYTES, BM, BN, p, splits, s, &done[1]);
+  if (fast == 2)
+    return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 1>, Cfg::SMEM_BYTES, BM, BN, p, splits, s, &done[2]);
+  return launch_kernel(dj_igemm_kernel<BM, BN, WM, WN, AM, BMD>, Cfg::SMEM_BYTES, BM, BN, p, splits, s, &done[0]);
+}
+
+static bool g_allow_fast = true;
+extern "C" void dj_set_fast_path(int enable) { g_allow_fast = enable != 0; }
+
+// Preconditions of dj_igemm_fast_kernel (see its header comment).
+template <int AM, int BMD>
+static int fast_mode(const DjIgemmParams& p) {
+  if (!g_allow_fast || !p.vecA || !p.vecB) return 0;
+  if (p.a_bytes <= 0 || p.b_bytes <= 0) return 0;  // operand >= 2 GiB (extent overflowed int)
+  if (AM != 2 && p.srcC % 32 != 0) return 0;
+  if (AM == 1 && (p.sH != 1 || p.sW != 1)) return 0;
+  if (AM == 2 && (p.srcC % 4 != 0 || p.K >= (1 << 24))) return 0;
+  if (BMD == 0 && (p.N % 4 != 0 || p.ldb % 4 != 0)) return 0;
+  if (BMD == 1 && p.srcC % 32 != 0) return 0;
+  return p.pro_scale ? 2 : 1;
+}
+
 template <int AM, int BMD>
 static int launch_cfg(int cfg, const DjIgemmParams& p, int splits, hipStream_t s) {
+  const int fast = fast_mode<AM, BMD>(p);
   switch (cfg) {
-    case CFG_128x128: return launch_one<128, 128, 2, 2, AM, BMD>(p, splits, s);
-    case CFG_128x64: return launch_one<128, 64, 2, 2, AM, BMD>(p, splits, s);
-    case CFG_64x64: return launch_one<64, 64, 2, 2, AM, BMD>(p, splits, s);
-    case CFG_128x32: return launch_one<128, 32, 4, 1, AM, BMD>(p, splits, s);
+    case CFG_128x128: return launch_one<128, 128, 2, 2, AM, BMD>(p, splits, s, fast);
+    case CFG_128x64: return launch_one<128, 64, 2, 2, AM, BMD>(p, splits, s, fast);
+    case CFG_64x64: return launch_one<64, 64, 2, 2, AM, BMD>(p, splits, s, fast);
+    case CFG_128x32: return launch_one<128, 32, 4, 1, AM, BMD>(p, splits, s, fast);
   }
   dj_set_error("bad tile cfg %d", cfg);
   return DJ_ERR_ARG;
@@ -130,6 +157,11 @@ __global__ void dj_relu_rows_kernel(float* y, long rows, int cols, int ld) {
   }
 }
 
+static int extent_bytes(long pixels, long ld, long c) {
+  long b = ((pixels - 1) * ld + c) * 4;
+  return (b > 0 && b < 0x7FFFFFF0L) ? (int)b : 0;
+}
+
 static void fill_geom(DjIgemmParams& p, const dj_conv2d_desc* d) {
   p.KH = d->kernel_h;
   p.KW = d->kernel_w;
@@ -183,6 +215,8 @@ extern "C" int dj_conv2d_nhwc_fwd(const dj_conv2d_desc* d, const float* x, const
   p.vecA = (d->in_c % 4 == 0) && (d->ld_x % 4 == 0) && aligned16(x) &&
            (!pro_scale || (aligned16(pro_scale) && aligned16(pro_shift)));
   p.vecB = (d->out_c % 4 == 0) && aligned16(w);
+  p.a_bytes = extent_bytes((long)d->batch * d->in_h * d->in_w, d->ld_x, d->in_c);
+  p.b_bytes = extent_bytes((long)p.K, d->out_c, d->out_c);
   int splits = 1;
   int cfg = choose_cfg(p.M, p.N, p.K, stats == nullptr, &splits);
   p.kchunk = dj_cdiv(dj_cdiv(p.K, splits), DJ_BK) * DJ_BK;
@@ -226,6 +260,8 @@ extern "C" int dj_conv2d_nhwc_dgrad(const dj_conv2d_desc* d, const float* dy, co
   p.beta = beta;
   p.vecA = (d->out_c % 4 == 0) && (d->ld_y % 4 == 0) && aligned16(dy);
   p.vecB = (d->out_c % 4 == 0) && aligned16(w);
+  p.a_bytes = extent_bytes((long)d->batch * d->out_h * d->out_w, d->ld_y, d->out_c);
+  p.b_bytes = extent_bytes((long)d->kernel_h * d->kernel_w * d->in_c, d->out_c, d->out_c);
   const long in_pixels = (long)d->batch * d->in_h * d->in_w;
   bool strided_1x1 = d->kernel_h == 1 && d->kernel_w == 1 && d->pad_top == 0 && d->pad_left == 0 &&
                      (d->stride_h > 1 || d->stride_w > 1) && d->stride_h == d->stride_w && bias == nullptr;
@@ -313,6 +349,10 @@ extern "C" int dj_conv2d_nhwc_wgrad(const dj_conv2d_desc* d, const float* x, con
   p.vecA = (d->in_c % 4 == 0) && (d->ld_x % 4 == 0) && aligned16(x) &&
            (!pro_scale || (aligned16(pro_scale) && aligned16(pro_shift)));
   p.vecB = (d->out_c % 4 == 0) && (d->ld_y % 4 == 0) && aligned16(dy);
+  p.a_bytes = extent_bytes((long)d->batch * d->in_h * d->in_w, d->ld_x, d->in_c);
+  p.b_bytes = extent_bytes((long)d->batch * d->out_h * d->out_w, d->ld_y, d->out_c);
+  p.inv_rowHW = 1.0f / (float)(d->out_h * d->out_w);
+  p.inv_rowW = 1.0f / (float)d->out_w;
   // tile by the (taps*Cin) x Cout extent only -- the pixel reduction is split over blockIdx.y to fill the chip
   int splits = 1;
   int cfg;

@@ -48,6 +48,8 @@ struct DjIgemmParams {
   int beta;                // 1: C = acc + C
   int atomic;              // 1: atomicAdd into C (split-K)
   int vecA, vecB;          // 16-byte loads legal for A / B
+  float inv_rowHW, inv_rowW;  // 1/(rowH*rowW), 1/rowW for the pixel decomposition of the fast wgrad path
+  int a_bytes, b_bytes;       // byte extents of A and B for the buffer descriptors of the fast path
 };
 
 template <int BM, int BN, int WM, int WN, int AM, int BMD>
@@ -99,6 +101,90 @@ __device__ __forceinline__ float dj_gather_elem(const DjIgemmParams& p, int pixb
     if (p.pro_relu) v = fmaxf(v, 0.f);
   }
   return v;
+}
+
+// Shared epilogue: optional per-tile BatchNormalization statistics of the raw accumulator, then
+// bias / accumulate / ReLU / (atomic) store with an optional strided-pixel row map.
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void dj_igemm_epilogue(const DjIgemmParams& p, f32x16 (&acc)[BM / (32 * WM)][BN / (32 * WN)],
+                                                  float* smem, int tile_m, int m0, int n0) {
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+  if (p.stats) {
+    // per-column sum and sum of squares of the raw accumulator over this tile's rows
+    float* red = smem;  // [2][WM][BN]
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r];
+          s += v;
+          q += v * v;
+        }
+      s += __shfl_xor(s, 32);
+      q += __shfl_xor(q, 32);
+      if (lh == 0) {
+        int col = (wn * TN + j) * 32 + l31;
+        red[(0 * WM + wm) * BN + col] = s;
+        red[(1 * WM + wm) * BN + col] = q;
+      }
+    }
+    __syncthreads();
+    for (int col = tid; col < BN; col += 256) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {
+        s += red[(0 * WM + w) * BN + col];
+        q += red[(1 * WM + w) * BN + col];
+      }
+      int n = n0 + col;
+      if (n < p.N) {
+        p.stats[((size_t)tile_m * 2 + 0) * p.N + n] = s;
+        p.stats[((size_t)tile_m * 2 + 1) * p.N + n] = q;
+      }
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= p.M) continue;
+      size_t rowoff;
+      if (p.cmap == 0) {
+        rowoff = (size_t)m * p.ldc;
+      } else {
+        int img = m / (p.cgH * p.cgW);
+        int rem = m - img * (p.cgH * p.cgW);
+        int h = rem / p.cgW;
+        int w = rem - h * p.cgW;
+        rowoff = (size_t)((img * p.cH + h * p.cS) * p.cW + w * p.cS) * p.ldc;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        int n = n0 + (wn * TN + j) * 32 + l31;
+        if (n >= p.N) continue;
+        float v = acc[i][j][r];
+        float* dst = p.C + rowoff + n;
+        if (p.atomic) {
+          if (p.bias && blockIdx.y == 0) v += p.bias[n];
+          atomicAdd(dst, v);
+        } else {
+          if (p.bias) v += p.bias[n];
+          if (p.beta) v += *dst;
+          if (p.relu) v = fmaxf(v, 0.f);
+          *dst = v;
+        }
+      }
+    }
+  }
 }
 
 template <int BM, int BN, int WM, int WN, int AM, int BMD>
@@ -436,77 +522,5 @@ __global__ __launch_bounds__(256) void dj_igemm_kernel(const DjIgemmParams p) {
     buf ^= 1;
   }
 
-  // ---------------- epilogue ----------------
-  if (p.stats) {
-    // per-column sum and sum of squares of the raw accumulator over this tile's rows
-    float* red = smem;  // [2][WM][BN]
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      float s = 0.f, q = 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = acc[i][j][r];
-          s += v;
-          q += v * v;
-        }
-      s += __shfl_xor(s, 32);
-      q += __shfl_xor(q, 32);
-      if (lh == 0) {
-        int col = (wn * TN + j) * 32 + l31;
-        red[(0 * WM + wm) * BN + col] = s;
-        red[(1 * WM + wm) * BN + col] = q;
-      }
-    }
-    __syncthreads();
-    for (int col = tid; col < BN; col += 256) {
-      float s = 0.f, q = 0.f;
-#pragma unroll
-      for (int w = 0; w < WM; ++w) {
-        s += red[(0 * WM + w) * BN + col];
-        q += red[(1 * WM + w) * BN + col];
-      }
-      int n = n0 + col;
-      if (n < p.N) {
-        p.stats[((size_t)tile_m * 2 + 0) * p.N + n] = s;
-        p.stats[((size_t)tile_m * 2 + 1) * p.N + n] = q;
-      }
-    }
-  }
-
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (m >= p.M) continue;
-      size_t rowoff;
-      if (p.cmap == 0) {
-        rowoff = (size_t)m * p.ldc;
-      } else {
-        int img = m / (p.cgH * p.cgW);
-        int rem = m - img * (p.cgH * p.cgW);
-        int h = rem / p.cgW;
-        int w = rem - h * p.cgW;
-        rowoff = (size_t)((img * p.cH + h * p.cS) * p.cW + w * p.cS) * p.ldc;
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        int n = n0 + (wn * TN + j) * 32 + l31;
-        if (n >= p.N) continue;
-        float v = acc[i][j][r];
-        float* dst = p.C + rowoff + n;
-        if (p.atomic) {
-          if (p.bias && blockIdx.y == 0) v += p.bias[n];
-          atomicAdd(dst, v);
-        } else {
-          if (p.bias) v += p.bias[n];
-          if (p.beta) v += *dst;
-          if (p.relu) v = fmaxf(v, 0.f);
-          *dst = v;
-        }
-      }
-    }
-  }
+  dj_igemm_epilogue<BM, BN, WM, WN>(p, acc, smem, tile_m, m0, n0);
 }

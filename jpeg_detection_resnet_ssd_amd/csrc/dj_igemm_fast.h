@@ -1,0 +1,313 @@
+// Branch-free fast path of the implicit-GEMM convolution (same math and LDS layout as dj_igemm.h).
+//
+// What differs from the generic kernel:
+//   * every global read is a raw BUFFER load (128-bit descriptor, 32-bit byte offset): halo / tail
+//     elements get the offset 0xFFFFFFF0, the hardware range check returns zeros -- no branches
+//     around loads, so the whole K-step is ONE basic block the scheduler can interleave with MFMAs;
+//   * the tap decomposition (kh, kw, c0) of a K-step is wave-uniform (requires srcC % 32 == 0 for the
+//     k-contiguous operands) and is advanced incrementally in scalar registers -- no per-step division;
+//   * per-row gather offsets are precomputed once; a K-step adds one uniform delta per row;
+//   * the two LDS stages are addressed with compile-time offsets (loop unrolled by 2), so the LDS
+//     writes of stage s^1 can be proven independent of the fragment reads of stage s;
+//   * sched_group_barrier directives spread the staging instructions over the MFMA issue slots: a
+//     v_mfma_f32_32x32x2_f32 occupies the matrix pipe for 64 cycles and the wave can issue ~14 other
+//     instructions in its shadow (MI355X_MICROARCH.md, per-instruction cycle constants).
+//
+// Preconditions (checked by the host launcher, which otherwise falls back to dj_igemm_kernel):
+//   A-mode 0/1: srcC % 32 == 0, stride 1 for mode 1; A-mode 2: srcC % 4 == 0, K' < 2^24;
+//   B-mode 0: N % 4 == 0, ldb % 4 == 0; B-mode 1: srcC % 32 == 0;
+//   16-byte aligned bases, every operand smaller than 2 GiB.
+#pragma once
+#include "dj_igemm.h"
+#include <type_traits>
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define DJ_OOB 0xFFFFFFF0u
+
+__device__ __forceinline__ f32x4 dj_buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+}
+
+// PRO: 0 = plain A, 1 = A*scale[c]+shift[c] (then max(., floor) with floor = 0 or -inf) on in-bounds elements
+template <int BM, int BN, int WM, int WN, int AM, int BMD, int PRO>
+__global__ __launch_bounds__(256) void dj_igemm_fast_kernel(const DjIgemmParams p) {
+  using Cfg = DjIgemmCfg<BM, BN, WM, WN, AM, BMD>;
+  constexpr int TM = Cfg::TM, TN = Cfg::TN, NA = Cfg::NA, NB = Cfg::NB;
+  constexpr int LDA_S = Cfg::LDA_S, LDB_S = Cfg::LDB_S;
+  constexpr int STAGE = Cfg::STAGE_FLOATS, AFL = Cfg::A_FLOATS;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tile_m = blockIdx.x / tiles_n;
+  const int tile_n = blockIdx.x - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kbeg = blockIdx.y * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
+  const int nk = (kend - kbeg + DJ_BK - 1) / DJ_BK;
+
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)p.pro_scale, 0, PRO ? p.srcC * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void*)p.pro_shift, 0, PRO ? p.srcC * 4 : 0, 0x00020000);
+  const float relu_floor = p.pro_relu ? 0.f : -INFINITY;
+
+  // ---------------- per-thread staging state ----------------
+  const int ac = tid & 7, ar0 = tid >> 3;              // A k-contiguous: (row ar0+32j, chunk ac)
+  constexpr int AKSTEP = 1024 / BM;
+  const int acm = tid % (BM / 4), akr0 = tid / (BM / 4);  // A m-contiguous: (k row akr0+AKSTEP j, chunk acm)
+  constexpr int BKSTEP = 1024 / BN;
+  const int bcn = tid % (BN / 4), bkr0 = tid / (BN / 4);  // B n-contiguous
+  const int bc = tid & 7, br0 = tid >> 3;                  // B k-contiguous
+
+  int a_off[NA], a_rh[NA], a_rw[NA];   // modes 0/1: byte offset of (row, tap 0, c 0) + chunk; row coordinates
+  int a2_c = 0, a2_dh = 0, a2_dw = 0;  // mode 2: channel, tap displacement of this thread's m' chunk
+  bool a2_ok = false;
+  f32x4 a2_sc = {1.f, 1.f, 1.f, 1.f}, a2_sh = {0.f, 0.f, 0.f, 0.f};
+  if (AM != 2) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      int m = m0 + ar0 + 32 * j;
+      if (m < p.M) {
+        int img = m / (p.rowH * p.rowW);
+        int rem = m - img * (p.rowH * p.rowW);
+        int h = rem / p.rowW;
+        int w = rem - h * p.rowW;
+        int rh = (AM == 0) ? h * p.sH - p.pT : h + p.pT;
+        int rw = (AM == 0) ? w * p.sW - p.pL : w + p.pL;
+        a_rh[j] = rh;
+        a_rw[j] = rw;
+        a_off[j] = ((img * p.srcH * p.srcW + rh * p.srcW + rw) * p.ldsrc + 4 * ac) * 4;
+      } else {
+        a_rh[j] = -(1 << 28);
+        a_rw[j] = -(1 << 28);
+        a_off[j] = 0;
+      }
+    }
+  } else {
+    int mm = m0 + 4 * acm;
+    a2_ok = mm < p.M;
+    int tap = mm / p.srcC;
+    a2_c = mm - tap * p.srcC;
+    int kh = tap / p.KW;
+    int kw = tap - kh * p.KW;
+    a2_dh = kh * p.dH - p.pT;
+    a2_dw = kw * p.dW - p.pL;
+    if (PRO) {
+      a2_sc = dj_buf_ld4(rS, a2_ok ? (unsigned)a2_c * 4u : DJ_OOB);
+      a2_sh = dj_buf_ld4(rT, a2_ok ? (unsigned)a2_c * 4u : DJ_OOB);
+    }
+  }
+  int b_off[NB];
+  bool b_ok[NB];
+  if (BMD == 0) {
+    int n = n0 + 4 * bcn;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      b_ok[j] = n < p.N;  // N % 4 == 0: chunks are all-or-nothing
+      b_off[j] = ((bkr0 + BKSTEP * j) * p.ldb + n) * 4;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      int n = n0 + br0 + 32 * j;
+      b_ok[j] = n < p.N;
+      b_off[j] = (n * p.ldb + 4 * bc) * 4;
+    }
+  }
+
+  // wave-uniform tap state of the k-contiguous operands (A modes 0/1, B mode 1), advanced per K-step
+  int t_c0 = 0, t_kh = 0, t_kw = 0, t_tap = 0;
+  if (AM != 2 || BMD == 1) {
+    t_tap = kbeg / p.srcC;
+    t_c0 = kbeg - t_tap * p.srcC;
+    t_kh = t_tap / p.KW;
+    t_kw = t_tap - t_kh * p.KW;
+  }
+
+  f32x4 ra[NA], rb[NB];
+  unsigned a_valid = 0;  // bit j: row j of the prefetched A tile is in bounds (needed when PRO)
+  f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+
+  auto issue_loads = [&](int kcur, bool live) {
+    // ---- A ----
+    if (AM != 2) {
+      const int dh = t_kh * p.dH, dw = t_kw * p.dW;
+      const int delta = (AM == 0) ? ((dh * p.srcW + dw) * p.ldsrc + t_c0) * 4 : (-(dh * p.srcW + dw) * p.ldsrc + t_c0) * 4;
+      if (PRO) {
+        psc = dj_buf_ld4(rS, (unsigned)(t_c0 + 4 * ac) * 4u);
+        psh = dj_buf_ld4(rT, (unsigned)(t_c0 + 4 * ac) * 4u);
+      }
+      a_valid = 0;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        int h = (AM == 0) ? a_rh[j] + dh : a_rh[j] - dh;
+        int w = (AM == 0) ? a_rw[j] + dw : a_rw[j] - dw;
+        bool ok = live && (unsigned)h < (unsigned)p.srcH && (unsigned)w < (unsigned)p.srcW;
+        ra[j] = dj_buf_ld4(rA, ok ? (unsigned)(a_off[j] + delta) : DJ_OOB);
+        a_valid |= ok ? (1u << j) : 0u;
+      }
+    } else {
+      a_valid = 0;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        int kp = kcur + akr0 + AKSTEP * j;
+        const int hw = p.rowH * p.rowW;
+        int img = (int)((float)kp * p.inv_rowHW);
+        int rem = kp - img * hw;
+        int adj = (rem < 0) ? -1 : ((rem >= hw) ? 1 : 0);  // float reciprocal is within one of the quotient
+        img += adj;
+        rem -= adj * hw;
+        int oh = (int)((float)rem * p.inv_rowW);
+        int ow = rem - oh * p.rowW;
+        int adj2 = (ow < 0) ? -1 : ((ow >= p.rowW) ? 1 : 0);
+        oh += adj2;
+        ow -= adj2 * p.rowW;
+        int h = oh * p.sH + a2_dh, w = ow * p.sW + a2_dw;
+        bool ok = live && a2_ok && kp < kend && (unsigned)h < (unsigned)p.srcH && (unsigned)w < (unsigned)p.srcW;
+        unsigned off = (unsigned)(((img * p.srcH + h) * p.srcW + w) * p.ldsrc + a2_c) * 4u;
+        ra[j] = dj_buf_ld4(rA, ok ? off : DJ_OOB);
+        a_valid |= ok ? (1u << j) : 0u;
+      }
+    }
+    // ---- B ----
+    if (BMD == 0) {
+      const int base = kcur * p.ldb * 4;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        bool ok = live && b_ok[j] && (AM != 2 || kcur + bkr0 + BKSTEP * j < kend);
+        rb[j] = dj_buf_ld4(rB, ok ? (unsigned)(b_off[j] + base) : DJ_OOB);
+      }
+    } else {
+      const unsigned base = (unsigned)(t_tap * p.bTapStride + t_c0) * 4u;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) rb[j] = dj_buf_ld4(rB, (live && b_ok[j]) ? (unsigned)b_off[j] + base : DJ_OOB);
+    }
+    // advance the uniform tap state to the next K-step
+    if (AM != 2 || BMD == 1) {
+      t_c0 += DJ_BK;
+      const int wrap = (t_c0 >= p.srcC) ? 1 : 0;
+      t_c0 = wrap ? 0 : t_c0;
+      t_tap += wrap;
+      t_kw += wrap;
+      const int wrap2 = (t_kw >= p.KW) ? 1 : 0;
+      t_kw = wrap2 ? 0 : t_kw;
+      t_kh += wrap2;
+    }
+  };
+
+  auto transform = [&]() {
+    if (PRO) {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        f32x4 sc = (AM == 2) ? a2_sc : psc, sh = (AM == 2) ? a2_sh : psh;
+        f32x4 v = ra[j] * sc + sh;
+        bool ok = (a_valid >> j) & 1u;
+        v.x = ok ? fmaxf(v.x, relu_floor) : 0.f;
+        v.y = ok ? fmaxf(v.y, relu_floor) : 0.f;
+        v.z = ok ? fmaxf(v.z, relu_floor) : 0.f;
+        v.w = ok ? fmaxf(v.w, relu_floor) : 0.f;
+        ra[j] = v;
+      }
+    }
+  };
+
+  auto store_tiles = [&](float* sA, float* sB) {
+    if (AM != 2) {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) *reinterpret_cast<f32x4*>(sA + (ar0 + 32 * j) * LDA_S + 4 * ac) = ra[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) *reinterpret_cast<f32x4*>(sA + (akr0 + AKSTEP * j) * LDA_S + 4 * acm) = ra[j];
+    }
+    if (BMD == 0) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) *reinterpret_cast<f32x4*>(sB + (bkr0 + BKSTEP * j) * LDB_S + 4 * bcn) = rb[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) *reinterpret_cast<f32x4*>(sB + (br0 + 32 * j) * LDB_S + 4 * bc) = rb[j];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // one 8-deep k group: fragment reads + 4*TM*TN MFMAs
+  auto compute_kk = [&](const float* sA, const float* sB, int kk) {
+    f32x4 af[TM], bf[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      int row = (wm * TM + i) * 32 + l31;
+      if (Cfg::A_KC) {
+        af[i] = *reinterpret_cast<const f32x4*>(sA + row * LDA_S + kk * 8 + lh * 4);
+      } else {
+        const float* q = sA + (kk * 8 + lh * 4) * LDA_S + row;
+        af[i].x = q[0];
+        af[i].y = q[LDA_S];
+        af[i].z = q[2 * LDA_S];
+        af[i].w = q[3 * LDA_S];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      int col = (wn * TN + j) * 32 + l31;
+      if (Cfg::B_KC) {
+        bf[j] = *reinterpret_cast<const f32x4*>(sB + col * LDB_S + kk * 8 + lh * 4);
+      } else {
+        const float* q = sB + (kk * 8 + lh * 4) * LDB_S + col;
+        bf[j].x = q[0];
+        bf[j].y = q[LDB_S];
+        bf[j].z = q[2 * LDB_S];
+        bf[j].w = q[3 * LDB_S];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+  };
+
+  // one K-step on compile-time LDS stage `S`: prefetch tile kt+1 while the MFMAs of tile kt run
+  auto kstep = [&](auto stage_tag, int kt) {
+    constexpr int S = decltype(stage_tag)::value;
+    float* curA = smem + S * STAGE;
+    float* curB = curA + AFL;
+    float* nxtA = smem + (S ^ 1) * STAGE;
+    float* nxtB = nxtA + AFL;
+    // the loads of a non-existent next tile are issued with out-of-range offsets (they return zeros
+    // without touching memory) so that the K-step stays one straight-line block
+    issue_loads(kbeg + (kt + 1) * DJ_BK, kt + 1 < nk);
+    compute_kk(curA, curB, 0);
+    compute_kk(curA, curB, 1);
+    compute_kk(curA, curB, 2);
+    transform();
+    store_tiles(nxtA, nxtB);
+    compute_kk(curA, curB, 3);
+    __syncthreads();
+  };
+
+  issue_loads(kbeg, nk > 0);
+  transform();
+  store_tiles(smem, smem + AFL);
+  __syncthreads();
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    kstep(std::integral_constant<int, 0>{}, kt);
+    kstep(std::integral_constant<int, 1>{}, kt + 1);
+  }
+  if (kt < nk) kstep(std::integral_constant<int, 0>{}, kt);
+
+  dj_igemm_epilogue<BM, BN, WM, WN>(p, acc, smem, tile_m, m0, n0);
+}

@@ -46,8 +46,18 @@ def _oracle_conv(x, wt, bias, case):
     return ko.conv2d(x, wt, bias, (s, s), pad, (d, d))
 
 
+@pytest.fixture(params=["fast", "generic"])
+def path(request):
+    """Every case runs through the launcher's default choice (branch-free kernel where its preconditions
+    hold) and again with the generic kernel forced."""
+    from jpeg_detection_resnet_ssd_amd import _lib
+    _lib.load().dj_set_fast_path(1 if request.param == "fast" else 0)
+    yield request.param
+    _lib.load().dj_set_fast_path(1)
+
+
 @pytest.mark.parametrize("case", CASES)
-def test_conv_fwd_dgrad_wgrad(case, cuda):
+def test_conv_fwd_dgrad_wgrad(case, cuda, path):
     from jpeg_detection_resnet_ssd_amd import kernels as K
     b, h, w, ci, co, kk, ss, pad, dd = _geometry(case)
     g = torch.Generator().manual_seed(1234)
@@ -86,7 +96,7 @@ def test_conv_fwd_dgrad_wgrad(case, cuda):
     assert (dw.cpu().double() - wr.grad).abs().max() <= _tol(wr.grad)
 
 
-def test_conv_prologue_relu_stats_and_slices(cuda):
+def test_conv_prologue_relu_stats_and_slices(cuda, path):
     """BN+ReLU folded into the A load, ReLU epilogue, per-tile BN statistics, and
     channel-slice views (ld > channels) on both sides."""
     from jpeg_detection_resnet_ssd_amd import kernels as K

@@ -1,0 +1,35 @@
+"""Per-launch timing of every implicit-GEMM call in one SSD300 training step (HIP events)."""
+import sys, os, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from jpeg_detection_resnet_ssd_amd import workloads, kernels as Kn
+archi = sys.argv[1] if len(sys.argv) > 1 else "deconv"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+model, sizes = workloads.build_ssd(archi)
+x, y = workloads.synthetic_batch(archi, sizes, B, fast=True)
+plan = model._plan(B, True, True)
+model._upload(plan, x, y)
+for _ in range(2): model.run_train_step(plan)
+torch.cuda.synchronize()
+recs = []
+def wrap(name):
+    f = getattr(Kn, name)
+    def timed(desc, *a, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); r = f(desc, *a, **kw); e1.record()
+        recs.append((name, (desc.batch, desc.in_h, desc.in_w, desc.in_c, desc.out_h, desc.out_c, desc.kernel_h, desc.stride_h, desc.dilation_h), e0, e1,
+                     2.0 * desc.batch * desc.out_h * desc.out_w * desc.out_c * desc.kernel_h * desc.kernel_w * desc.in_c))
+        return r
+    setattr(Kn, name, timed)
+for n in ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad"): wrap(n)
+model.run_train_step(plan); torch.cuda.synchronize()
+agg = collections.OrderedDict()
+for name, key, e0, e1, fl in recs:
+    k = (name, key)
+    t = e0.elapsed_time(e1)
+    a = agg.setdefault(k, [0, 0.0, 0.0]); a[0] += 1; a[1] += t; a[2] += fl
+tot = sum(a[1] for a in agg.values())
+print("total conv ms %.2f, TF %.1f" % (tot, sum(a[2] for a in agg.values()) / tot / 1e9))
+print("%-13s %-44s %4s %8s %7s %6s" % ("op", "B,H,W,Cin,OH,Cout,k,s,d", "n", "ms", "TF", "%"))
+for (name, key), a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+    print("%-13s %-44s %4d %8.3f %7.1f %6.1f" % (name, str(key), a[0], a[1], a[2] / a[1] / 1e9, 100 * a[1] / tot))
