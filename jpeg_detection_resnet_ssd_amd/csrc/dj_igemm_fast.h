@@ -58,16 +58,15 @@ __global__ __launch_bounds__(256) void dj_igemm_fast_kernel(const DjIgemmParams 
 
   // ---------------- per-thread staging state ----------------
   const int ac = tid & 7, ar0 = tid >> 3;              // A k-contiguous: (row ar0+32j, chunk ac)
-  constexpr int AKSTEP = 1024 / BM;
-  const int acm = tid % (BM / 4), akr0 = tid / (BM / 4);  // A m-contiguous: (k row akr0+AKSTEP j, chunk acm)
   constexpr int BKSTEP = 1024 / BN;
   const int bcn = tid % (BN / 4), bkr0 = tid / (BN / 4);  // B n-contiguous
   const int bc = tid & 7, br0 = tid >> 3;                  // B k-contiguous
 
   int a_off[NA], a_rh[NA], a_rw[NA];   // modes 0/1: byte offset of (row, tap 0, c 0) + chunk; row coordinates
-  int a2_c = 0, a2_dh = 0, a2_dw = 0;  // mode 2: channel, tap displacement of this thread's m' chunk
-  bool a2_ok = false;
-  f32x4 a2_sc = {1.f, 1.f, 1.f, 1.f}, a2_sh = {0.f, 0.f, 0.f, 0.f};
+  // mode 2: thread -> (pixel row ar0 of the K-step, m' chunks ac + 8 i): ONE pixel decomposition per K-step
+  int a2_c[NA], a2_dh[NA], a2_dw[NA];
+  bool a2_ok[NA];
+  f32x4 a2_sc[NA], a2_sh[NA];
   if (AM != 2) {
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
@@ -89,17 +88,20 @@ __global__ __launch_bounds__(256) void dj_igemm_fast_kernel(const DjIgemmParams 
       }
     }
   } else {
-    int mm = m0 + 4 * acm;
-    a2_ok = mm < p.M;
-    int tap = mm / p.srcC;
-    a2_c = mm - tap * p.srcC;
-    int kh = tap / p.KW;
-    int kw = tap - kh * p.KW;
-    a2_dh = kh * p.dH - p.pT;
-    a2_dw = kw * p.dW - p.pL;
-    if (PRO) {
-      a2_sc = dj_buf_ld4(rS, a2_ok ? (unsigned)a2_c * 4u : DJ_OOB);
-      a2_sh = dj_buf_ld4(rT, a2_ok ? (unsigned)a2_c * 4u : DJ_OOB);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      int mm = m0 + 4 * (ac + 8 * i);
+      a2_ok[i] = mm < p.M;
+      int tap = mm / p.srcC;
+      a2_c[i] = mm - tap * p.srcC;
+      int kh = tap / p.KW;
+      int kw = tap - kh * p.KW;
+      a2_dh[i] = kh * p.dH - p.pT;
+      a2_dw[i] = kw * p.dW - p.pL;
+      if (PRO) {
+        a2_sc[i] = dj_buf_ld4(rS, a2_ok[i] ? (unsigned)a2_c[i] * 4u : DJ_OOB);
+        a2_sh[i] = dj_buf_ld4(rT, a2_ok[i] ? (unsigned)a2_c[i] * 4u : DJ_OOB);
+      }
     }
   }
   int b_off[NB];
@@ -153,25 +155,27 @@ __global__ __launch_bounds__(256) void dj_igemm_fast_kernel(const DjIgemmParams 
       }
     } else {
       a_valid = 0;
+      const int kp = kcur + ar0;
+      const int hw = p.rowH * p.rowW;
+      int img = (int)((float)kp * p.inv_rowHW);
+      int rem = kp - img * hw;
+      int adj = (rem < 0) ? -1 : ((rem >= hw) ? 1 : 0);  // float reciprocal is within one of the quotient
+      img += adj;
+      rem -= adj * hw;
+      int oh = (int)((float)rem * p.inv_rowW);
+      int ow = rem - oh * p.rowW;
+      int adj2 = (ow < 0) ? -1 : ((ow >= p.rowW) ? 1 : 0);
+      oh += adj2;
+      ow -= adj2 * p.rowW;
+      const bool rowok = live && kp < kend;
+      const int h0 = oh * p.sH, w0 = ow * p.sW, pb = img * p.srcH * p.srcW;
 #pragma unroll
-      for (int j = 0; j < NA; ++j) {
-        int kp = kcur + akr0 + AKSTEP * j;
-        const int hw = p.rowH * p.rowW;
-        int img = (int)((float)kp * p.inv_rowHW);
-        int rem = kp - img * hw;
-        int adj = (rem < 0) ? -1 : ((rem >= hw) ? 1 : 0);  // float reciprocal is within one of the quotient
-        img += adj;
-        rem -= adj * hw;
-        int oh = (int)((float)rem * p.inv_rowW);
-        int ow = rem - oh * p.rowW;
-        int adj2 = (ow < 0) ? -1 : ((ow >= p.rowW) ? 1 : 0);
-        oh += adj2;
-        ow -= adj2 * p.rowW;
-        int h = oh * p.sH + a2_dh, w = ow * p.sW + a2_dw;
-        bool ok = live && a2_ok && kp < kend && (unsigned)h < (unsigned)p.srcH && (unsigned)w < (unsigned)p.srcW;
-        unsigned off = (unsigned)(((img * p.srcH + h) * p.srcW + w) * p.ldsrc + a2_c) * 4u;
-        ra[j] = dj_buf_ld4(rA, ok ? off : DJ_OOB);
-        a_valid |= ok ? (1u << j) : 0u;
+      for (int i = 0; i < NA; ++i) {
+        int h = h0 + a2_dh[i], w = w0 + a2_dw[i];
+        bool ok = rowok && a2_ok[i] && (unsigned)h < (unsigned)p.srcH && (unsigned)w < (unsigned)p.srcW;
+        unsigned off = (unsigned)((pb + h * p.srcW + w) * p.ldsrc + a2_c[i]) * 4u;
+        ra[i] = dj_buf_ld4(rA, ok ? off : DJ_OOB);
+        a_valid |= ok ? (1u << i) : 0u;
       }
     }
     // ---- B ----
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(256) void dj_igemm_fast_kernel(const DjIgemmParams 
     if (PRO) {
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
-        f32x4 sc = (AM == 2) ? a2_sc : psc, sh = (AM == 2) ? a2_sh : psh;
+        f32x4 sc = (AM == 2) ? a2_sc[j] : psc, sh = (AM == 2) ? a2_sh[j] : psh;
         f32x4 v = ra[j] * sc + sh;
         bool ok = (a_valid >> j) & 1u;
         v.x = ok ? fmaxf(v.x, relu_floor) : 0.f;
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(256) void dj_igemm_fast_kernel(const DjIgemmParams 
       for (int j = 0; j < NA; ++j) *reinterpret_cast<f32x4*>(sA + (ar0 + 32 * j) * LDA_S + 4 * ac) = ra[j];
     } else {
 #pragma unroll
-      for (int j = 0; j < NA; ++j) *reinterpret_cast<f32x4*>(sA + (akr0 + AKSTEP * j) * LDA_S + 4 * acm) = ra[j];
+      for (int j = 0; j < NA; ++j) *reinterpret_cast<f32x4*>(sA + ar0 * LDA_S + 4 * (ac + 8 * j)) = ra[j];
     }
     if (BMD == 0) {
 #pragma unroll

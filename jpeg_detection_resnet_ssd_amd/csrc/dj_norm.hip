@@ -10,6 +10,19 @@
 
 #define DJ_RB 64  // rows per reduction block
 
+template <int VEC>
+struct VecIO;
+template <>
+struct VecIO<4> {
+  static __device__ __forceinline__ f32x4 ld(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static __device__ __forceinline__ void st(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <>
+struct VecIO<1> {
+  static __device__ __forceinline__ f32x4 ld(const float* p) { return f32x4{p[0], 0.f, 0.f, 0.f}; }
+  static __device__ __forceinline__ void st(float* p, f32x4 v) { p[0] = v.x; }
+};
+
 // ---------------------------------------------------------------------------------
 // Blocked column reduction: out[blk][q][c] = sum over the block's rows of f_q(row, c), q in {0,1}
 // ---------------------------------------------------------------------------------
@@ -250,34 +263,29 @@ __global__ __launch_bounds__(256) void dj_affine_act_kernel(const float* x, int 
                                                              const float* shift, const float* res, int ldres,
                                                              const float* rscale, const float* rshift, float* y,
                                                              int ldy, long rows, int C, int relu) {
+  using IO = VecIO<VEC>;
   const int cv = C / VEC;
   long total = rows * cv;
+  const float floor_ = relu ? 0.f : -INFINITY;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     long r = i / cv;
     int c = (int)(i - r * cv) * VEC;
-    float v[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) v[e] = x[r * ldx + c + e];
-    if (scale) {
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) v[e] = v[e] * scale[c + e] + shift[c + e];
-    }
+    f32x4 v = IO::ld(x + r * ldx + c);
+    if (scale) v = v * IO::ld(scale + c) + IO::ld(shift + c);
     if (res) {
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        float t = res[r * ldres + c + e];
-        if (rscale) t = t * rscale[c + e] + rshift[c + e];
-        v[e] += t;
-      }
+      f32x4 t = IO::ld(res + r * ldres + c);
+      if (rscale) t = t * IO::ld(rscale + c) + IO::ld(rshift + c);
+      v += t;
     }
-    if (relu) {
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) v[e] = fmaxf(v[e], 0.f);
-    }
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) y[r * ldy + c + e] = v[e];
+    v.x = fmaxf(v.x, floor_);
+    v.y = fmaxf(v.y, floor_);
+    v.z = fmaxf(v.z, floor_);
+    v.w = fmaxf(v.w, floor_);
+    IO::st(y + r * ldy + c, v);
   }
 }
+
+static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 static inline int ew_blocks(long total) {
   long b = (total + 255) / 256;
@@ -292,7 +300,8 @@ extern "C" int dj_affine_act(const float* x, int ldx, const float* scale, const 
                "affine_act: scale/shift come together");
   DJ_CHECK_ARG(res || !res_scale, "affine_act: res_scale without res");
   hipStream_t s = (hipStream_t)stream;
-  bool v4 = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (!res || ldres % 4 == 0);
+  bool v4 = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (!res || ldres % 4 == 0) && al16(x) && al16(y) &&
+            al16(res) && al16(scale) && al16(shift) && al16(res_scale) && al16(res_shift);
   if (v4) {
     hipLaunchKernelGGL(dj_affine_act_kernel<4>, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, s, x, ldx, scale, shift,
                        res, ldres, res_scale, res_shift, y, ldy, rows, C, relu);
@@ -352,22 +361,25 @@ __global__ __launch_bounds__(256) void dj_bn_bwd_apply_kernel(const float* dy, i
                                                                const float* shift, int mask_mode, const float* k0,
                                                                const float* k1, const float* k2, float* dz, int ld_dz,
                                                                long rows, int C) {
+  using IO = VecIO<VEC>;
   const int cv = C / VEC;
   long total = rows * cv;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     long r = i / cv;
     int c = (int)(i - r * cv) * VEC;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      float g = dy[r * ld_dy + c + e];
-      float zz = z[r * ld_z + c + e];
-      if (mask_mode == 1) {
-        if (!(y[r * ld_y + c + e] > 0.f)) g = 0.f;
-      } else if (mask_mode == 2) {
-        if (!(zz * scale[c + e] + shift[c + e] > 0.f)) g = 0.f;
-      }
-      dz[r * ld_dz + c + e] = k0[c + e] * g + k1[c + e] * zz + k2[c + e];
+    f32x4 g = IO::ld(dy + r * ld_dy + c);
+    f32x4 zz = IO::ld(z + r * ld_z + c);
+    f32x4 m = {1.f, 1.f, 1.f, 1.f};
+    if (mask_mode == 1) {
+      m = IO::ld(y + r * ld_y + c);
+    } else if (mask_mode == 2) {
+      m = zz * IO::ld(scale + c) + IO::ld(shift + c);
     }
+    g.x = (m.x > 0.f) ? g.x : 0.f;
+    g.y = (m.y > 0.f) ? g.y : 0.f;
+    g.z = (m.z > 0.f) ? g.z : 0.f;
+    g.w = (m.w > 0.f) ? g.w : 0.f;
+    IO::st(dz + r * ld_dz + c, IO::ld(k0 + c) * g + IO::ld(k1 + c) * zz + IO::ld(k2 + c));
   }
 }
 
@@ -380,7 +392,8 @@ extern "C" int dj_bn_bwd_apply(const float* dy, int ld_dy, const float* z, int l
   DJ_CHECK_ARG(mask_mode != 1 || y, "bn_bwd_apply: mask_mode 1 needs y");
   DJ_CHECK_ARG(mask_mode != 2 || (scale && shift), "bn_bwd_apply: mask_mode 2 needs scale/shift");
   hipStream_t s = (hipStream_t)stream;
-  bool v4 = (C % 4 == 0) && (ld_dy % 4 == 0) && (ld_z % 4 == 0) && (ld_dz % 4 == 0) && (mask_mode != 1 || ld_y % 4 == 0);
+  bool v4 = (C % 4 == 0) && (ld_dy % 4 == 0) && (ld_z % 4 == 0) && (ld_dz % 4 == 0) && (mask_mode != 1 || ld_y % 4 == 0) &&
+            al16(dy) && al16(z) && al16(dz) && al16(y) && al16(scale) && al16(shift) && al16(k0) && al16(k1) && al16(k2);
   if (v4)
     hipLaunchKernelGGL(dj_bn_bwd_apply_kernel<4>, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, s, dy, ld_dy, z, ld_z,
                        y, ld_y, scale, shift, mask_mode, k0, k1, k2, dz, ld_dz, rows, C);
@@ -395,17 +408,21 @@ extern "C" int dj_bn_bwd_apply(const float* dy, int ld_dy, const float* z, int l
 template <int VEC>
 __global__ __launch_bounds__(256) void dj_relu_bwd_kernel(const float* dy, int ld_dy, const float* y, int ld_y,
                                                            float* dx, int ld_dx, long rows, int C, int beta) {
+  using IO = VecIO<VEC>;
   const int cv = C / VEC;
   long total = rows * cv;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     long r = i / cv;
     int c = (int)(i - r * cv) * VEC;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      float g = (y[r * ld_y + c + e] > 0.f) ? dy[r * ld_dy + c + e] : 0.f;
-      float* d = dx + r * ld_dx + c + e;
-      *d = beta ? (*d + g) : g;
-    }
+    f32x4 g = IO::ld(dy + r * ld_dy + c);
+    f32x4 m = IO::ld(y + r * ld_y + c);
+    g.x = (m.x > 0.f) ? g.x : 0.f;
+    g.y = (m.y > 0.f) ? g.y : 0.f;
+    g.z = (m.z > 0.f) ? g.z : 0.f;
+    g.w = (m.w > 0.f) ? g.w : 0.f;
+    float* d = dx + r * ld_dx + c;
+    if (beta) g += IO::ld(d);
+    IO::st(d, g);
   }
 }
 
@@ -413,7 +430,7 @@ extern "C" int dj_relu_bwd(const float* dy, int ld_dy, const float* y, int ld_y,
                            int C, int beta, void* stream) {
   DJ_CHECK_ARG(dy && y && dx && rows > 0 && C > 0, "relu_bwd: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  bool v4 = (C % 4 == 0) && (ld_dy % 4 == 0) && (ld_y % 4 == 0) && (ld_dx % 4 == 0);
+  bool v4 = (C % 4 == 0) && (ld_dy % 4 == 0) && (ld_y % 4 == 0) && (ld_dx % 4 == 0) && al16(dy) && al16(y) && al16(dx);
   if (v4)
     hipLaunchKernelGGL(dj_relu_bwd_kernel<4>, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, s, dy, ld_dy, y, ld_y, dx,
                        ld_dx, rows, C, beta);
@@ -428,17 +445,16 @@ extern "C" int dj_relu_bwd(const float* dy, int ld_dy, const float* y, int ld_y,
 template <int VEC>
 __global__ __launch_bounds__(256) void dj_copy2d_kernel(const float* src, long lds, float* dst, long ldd, long rows,
                                                          long cols, int beta) {
+  using IO = VecIO<VEC>;
   const long cv = cols / VEC;
   long total = rows * cv;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     long r = i / cv;
     long c = (i - r * cv) * VEC;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      float v = src[r * lds + c + e];
-      float* d = dst + r * ldd + c + e;
-      *d = beta ? (*d + v) : v;
-    }
+    f32x4 v = IO::ld(src + r * lds + c);
+    float* d = dst + r * ldd + c;
+    if (beta) v += IO::ld(d);
+    IO::st(d, v);
   }
 }
 
@@ -446,7 +462,7 @@ extern "C" int dj_copy2d(const float* src, long ld_src, float* dst, long ld_dst,
                          void* stream) {
   DJ_CHECK_ARG(src && dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= cols, "copy2d: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  bool v4 = (cols % 4 == 0) && (ld_src % 4 == 0) && (ld_dst % 4 == 0);
+  bool v4 = (cols % 4 == 0) && (ld_src % 4 == 0) && (ld_dst % 4 == 0) && al16(src) && al16(dst);
   if (v4)
     hipLaunchKernelGGL(dj_copy2d_kernel<4>, dim3(ew_blocks(rows * (cols / 4))), dim3(256), 0, s, src, ld_src, dst,
                        ld_dst, rows, cols, beta);

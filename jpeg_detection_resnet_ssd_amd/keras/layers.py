@@ -278,7 +278,13 @@ class Conv2D(Layer):
                 rows, c, ld = rows_of(dy)
                 plan.emit_bwd(lambda: call("dj_relu_bwd", dy, ld, y, c, dy, ld, rows, c, 0))
             if self.bias is not None and self.bias.trainable:
-                _bias_grad(plan, dy, self.bias)
+                if stats is not None:
+                    # the only consumer is a training-mode BatchNormalization: it subtracts the batch mean, so
+                    # d loss / d bias = sum(dz) is identically zero (TF's autodiff returns rounding noise);
+                    # the gradient buffer is zero-initialised and simply left untouched
+                    plan.note_grad(self.bias)
+                else:
+                    _bias_grad(plan, dy, self.bias)
             if self.kernel.trainable:
                 dw = self.kernel.grad
                 plan.emit_bwd(lambda: Kn.conv2d_wgrad(desc, xbuf, dy, dw, pro[0], pro[1], pro[2]))
