@@ -1,0 +1,135 @@
+"""CPU: the C-ABI library loads and exports every symbol include/dj_hip.h declares (no compute calls), the
+model builders reproduce the reference's graph structure, and argument validation raises like the reference."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from jpeg_detection_resnet_ssd_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "dj_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(dj_[a-z0-9_]+)\s*\(", header))
+    declared.discard("dj_conv2d_desc")
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), "library does not export " + name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.dj_abi_version() == 1
+    assert lib.dj_reduce_rows(46208) == 722
+
+
+def test_conv_desc_argument_errors_surface_through_the_abi():
+    """Bad descriptors are refused on the host before any launch (no GPU needed)."""
+    import ctypes
+    from jpeg_detection_resnet_ssd_amd import _lib
+    lib = _lib.load()
+    d = _lib.ConvDesc(1, 8, 8, 16, 8, 8, 16, 3, 3, 1, 1, 1, 1, 1, 1, 8, 16)   # ld_x < in_c
+    assert lib.dj_conv2d_fwd_stats_rows(ctypes.byref(d)) < 0
+    assert b"ld_x" in lib.dj_last_error()
+    with pytest.raises(_lib.DjError):
+        _lib.check(lib.dj_conv2d_fwd_stats_rows(ctypes.byref(d)), "stats_rows")
+
+
+def test_same_padding_rule():
+    from jpeg_detection_resnet_ssd_amd.kernels import conv_geometry, same_padding
+    assert same_padding(38, 2, 1) == (0, 1, 38)        # even kernel: pad after only
+    assert same_padding(38, 3, 1) == (1, 1, 38)
+    assert same_padding(5, 3, 1, 6) == (6, 6, 5)       # fc6, dilation 6
+    assert same_padding(38, 1, 2) == (0, 0, 19)
+    assert conv_geometry(5, 5, (3, 3), (2, 2), ((1, 1), (1, 1)), (1, 1)) == (1, 1, 3, 3)   # conv6_2
+    assert conv_geometry(19, 19, (1, 1), (2, 2), "valid", (1, 1)) == (0, 0, 10, 10)
+
+
+@pytest.mark.parametrize("archi,boxes,params,convs,bns", [
+    ("ssd_custom", 8732, 52048238, 87, 71), ("deconv", 6716, 51708206, 76, 53), ("up_sampling", 6716, 51675310, 74, 53),
+    ("y_cb4_cbcr_cb5", 6716, None, None, None), ("cb5_only", 6716, None, None, None)])
+def test_ssd_graph_structure(archi, boxes, params, convs, bns):
+    from jpeg_detection_resnet_ssd_amd import workloads
+    model, sizes = workloads.build_ssd(archi, compile_model=False)
+    assert model.outputs[0].shape == (None, boxes, 33)
+    if params:
+        assert model.count_params() == params
+        kinds = [l.__class__.__name__ for l in model.layers]
+        assert kinds.count("Conv2D") + kinds.count("Conv2DTranspose") == convs
+        assert kinds.count("BatchNormalization") == bns
+    names = [l.name for l in model.layers]
+    for n in ["pool5_ssd", "fc6", "fc7", "conv6_1", "conv6_padding", "conv6_2", "conv9_2", "conv4_3_norm",
+              "conv4_3_norm_mbox_conf_21", "fc7_mbox_loc", "conv9_2_mbox_priorbox", "mbox_conf", "mbox_conf_softmax",
+              "predictions_ssd", "res5c_branch2c", "bn5c_branch2c"]:
+        assert n in names, n
+    # the reference trainer reads the predictor sizes back like this (training_dct_pascal_j2d_resnet.py:244-249)
+    got = [model.get_layer("%s_mbox_conf_21" % s).output_shape[1:3]
+           for s in ["conv4_3_norm", "fc7", "conv6_2", "conv7_2", "conv8_2", "conv9_2"]]
+    assert [tuple(g) for g in got] == [tuple(s) for s in sizes]
+    if archi == "ssd_custom":
+        assert names[:6] == ["input_1", "input_2", "batch_normalization_1", "res1a2_branch2a", "bn1a2_branch2a", "activation_1"]
+        assert [t.shape for t in model.inputs] == [(None, 38, 38, 64), (None, 19, 19, 128)]
+        assert "batch_normalization_2" in names and "res2a5_branch1" in names
+        l2s = {w.key: w.l2 for w in model.weight_specs}
+        assert l2s["fc6/kernel"] == 0.0005 and l2s["fc6/bias"] == 0 and l2s["res5c_branch2c/kernel"] == 0
+        assert l2s["conv4_3_norm_mbox_loc/kernel"] == 0.0005
+        assert model.get_layer("conv4_3_norm").weight_specs[0].key == "conv4_3_norm/conv4_3_norm_gamma"
+    if archi == "deconv":
+        assert [t.shape for t in model.inputs] == [(None, 38, 38, 64), (None, 19, 19, 64), (None, 19, 19, 64)]
+        assert "conv2d_transpose_1" in names and "conv2d_transpose_2" in names
+        assert model.get_layer("conv2d_transpose_1").weight_specs[0].shape == (2, 2, 64, 64)
+    if archi == "y_cb4_cbcr_cb5":
+        assert "res2a4_branch2a" not in names   # dead branch of the reference: built but not part of the Model
+
+
+def test_builder_argument_validation_matches_reference_messages():
+    from jpeg_detection_resnet_ssd_amd import workloads
+    from jpeg_detection_resnet_ssd_amd.models.keras_ssd300_dct_j2d_resnet import (ssd_resnet_EF_layers_custom,
+                                                                                 ssd_resnet_EF_layers_identical)
+    base = dict(workloads.SSD_ARGS)
+    with pytest.raises(ValueError, match="Unknown network architecture"):
+        ssd_resnet_EF_layers_identical(archi="nope", **base)
+    bad = dict(base, scales=[0.1, 0.2])
+    with pytest.raises(ValueError, match="len\\(scales\\) == 7"):
+        ssd_resnet_EF_layers_custom(**bad)
+    bad = dict(base, variances=[0.1, 0.1, 0.2])
+    with pytest.raises(ValueError, match="4 variance values"):
+        ssd_resnet_EF_layers_custom(**bad)
+    bad = dict(base, variances=[0.1, 0.1, 0.2, -1])
+    with pytest.raises(ValueError, match="All variances must be >0"):
+        ssd_resnet_EF_layers_custom(**bad)
+    bad = dict(base, steps=[8, 16])
+    with pytest.raises(ValueError, match="step value per predictor layer"):
+        ssd_resnet_EF_layers_custom(**bad)
+    bad = dict(base, mode="bogus")
+    with pytest.raises(ValueError, match="`mode` must be one of"):
+        ssd_resnet_EF_layers_custom(**bad)
+    bad = dict(base, aspect_ratios_per_layer=None, aspect_ratios_global=None)
+    with pytest.raises(ValueError, match="cannot both be None"):
+        ssd_resnet_EF_layers_custom(**bad)
+
+
+def test_compute_path_refuses_to_run_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from jpeg_detection_resnet_ssd_amd import workloads
+    model, sizes = workloads.build_ssd("ssd_custom")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model.train_on_batch([np.zeros((1, 38, 38, 64)), np.zeros((1, 19, 19, 128))], np.zeros((1, 8732, 33)))
+
+
+def test_synthetic_dct_follows_jpeg2dct_semantics():
+    from jpeg_detection_resnet_ssd_amd.data import synthetic_dct as sd
+    assert list(sd.LUMA_Q75[0]) == [8, 6, 5, 8, 12, 20, 26, 31]      # tests_generators.py:66-68: -616 = -77 * 8
+    assert list(sd.CHROMA_Q75[0]) == [9, 9, 12, 24, 50, 50, 50, 50]
+    y, cbcr = sd.dct_batch(2, seed=3)
+    assert y.shape == (2, 38, 38, 64) and cbcr.shape == (2, 19, 19, 128) and y.dtype == np.float32
+    assert np.all(np.round(y / sd.LUMA_Q75.reshape(64)) * sd.LUMA_Q75.reshape(64) == y)   # de-quantised = level * table
+    assert (y == 0).mean() > 0.5
+    ys, cb, cr = sd.dct_batch(1, seed=3, split_chroma=True)
+    assert cb.shape == (1, 19, 19, 64) and cr.shape == (1, 19, 19, 64)
+    flat = np.full((300, 300, 3), 200, np.uint8)
+    yf, cbf, crf = sd.rgb_to_dct(flat)
+    assert yf[0, 0, 0] == np.round((200 - 128) * 8 / 8) * 8 and np.all(yf[..., 1:] == 0) and np.all(cbf == 0)
