@@ -43,8 +43,8 @@ typedef struct dj_conv2d_desc {
   int ld_y; /* pixel stride of y / dy */
 } dj_conv2d_desc;
 
-/* Number of row tiles the forward launcher uses for this geometry == leading dimension
- * of the `stats` partial buffer ([rows][2][out_c] floats). */
+/* Leading dimension of the `stats` partial buffer ([rows][2][out_c] floats): one row per 64 output
+ * pixels, independent of the tile configuration. */
 int dj_conv2d_fwd_stats_rows(const dj_conv2d_desc* d);
 
 /* y = act(conv(pro(x), w) + bias).  Replaces Conv2D.call (TF conv2d + bias_add [+ relu]).
@@ -67,6 +67,13 @@ int dj_conv2d_nhwc_dgrad(const dj_conv2d_desc* d, const float* dy, const float* 
 /* Debug/test switch: 0 forces the generic (branchy, any-shape) implicit-GEMM kernel, 1 (default) lets the
  * launcher pick the branch-free buffer-load kernel whenever its alignment preconditions hold. */
 void dj_set_fast_path(int enable);
+
+/* Launch-configuration overrides per conv geometry, filled by the plan-time autotuner: `dir` 0 fwd, 1 dgrad,
+ * 2 wgrad (+4: forward that takes BN statistics); cfg in [0, dj_conv2d_tune_configs()) selects the tile shape
+ * (128x128, 128x64, 64x64, 128x32), `splits` the split-K factor; cfg < 0 removes the override. */
+int dj_conv2d_tune_configs(void);
+int dj_conv2d_tune_set(int dir, const dj_conv2d_desc* d, int cfg, int splits);
+int dj_conv2d_default_config(int dir, const dj_conv2d_desc* d, int* cfg, int* splits);
 
 /* dw = sum over pixels pro(x)^T dy  (TF Conv2DBackpropFilter).  dw is HWIO, overwritten. */
 int dj_conv2d_nhwc_wgrad(const dj_conv2d_desc* d, const float* x, const float* dy, float* dw,

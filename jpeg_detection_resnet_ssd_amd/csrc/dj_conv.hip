@@ -3,6 +3,9 @@
 #include "dj_igemm.h"
 #include "dj_igemm_fast.h"
 #include <string.h>
+#include <map>
+#include <mutex>
+#include <array>
 
 static thread_local char g_err[512] = "";
 void dj_set_error(const char* fmt, ...) {
@@ -20,8 +23,9 @@ extern "C" int dj_abi_version(void) { return 1; }
 struct TileCfg {
   int bm, bn;
 };
-static const TileCfg kCfgs[] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}};
-enum { CFG_128x128 = 0, CFG_128x64, CFG_64x64, CFG_128x32, N_CFG };
+static const TileCfg kCfgs[] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {128, 128}, {128, 64}};
+// *_S1: same tile with a single LDS stage (fast kernel only; the generic kernel ignores the distinction)
+enum { CFG_128x128 = 0, CFG_128x64, CFG_64x64, CFG_128x32, CFG_128x128_S1, CFG_128x64_S1, N_CFG };
 
 template <typename KernT>
 static int launch_kernel(KernT kern, int smem_bytes, int bm, int bn, const DjIgemmParams& p, int splits, hipStream_t s,
@@ -42,14 +46,17 @@ static int launch_kernel(KernT kern, int smem_bytes, int bm, int bn, const DjIge
 }
 
 // fast = 0: generic kernel; 1: branch-free kernel; 2: branch-free kernel with the affine prologue
-template <int BM, int BN, int WM, int WN, int AM, int BMD>
+template <int BM, int BN, int WM, int WN, int AM, int BMD, int NSTAGE>
 static int launch_one(const DjIgemmParams& p, int splits, hipStream_t s, int fast) {
   using Cfg = DjIgemmCfg<BM, BN, WM, WN, AM, BMD>;
   static bool done[3] = {false, false, false};
+  const int smem_fast = Cfg::SMEM_BYTES / 2 * NSTAGE;
   if (fast == 1)
-    return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 0>, Cfg::SMEM_BYTES, BM, BN, p, splits, s, &done[1]);
+    return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 0, NSTAGE>, smem_fast, BM, BN, p, splits, s,
+                         &done[1]);
   if (fast == 2)
-    return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 1>, Cfg::SMEM_BYTES, BM, BN, p, splits, s, &done[2]);
+    return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 1, NSTAGE>, smem_fast, BM, BN, p, splits, s,
+                         &done[2]);
   return launch_kernel(dj_igemm_kernel<BM, BN, WM, WN, AM, BMD>, Cfg::SMEM_BYTES, BM, BN, p, splits, s, &done[0]);
 }
 
@@ -73,10 +80,16 @@ template <int AM, int BMD>
 static int launch_cfg(int cfg, const DjIgemmParams& p, int splits, hipStream_t s) {
   const int fast = fast_mode<AM, BMD>(p);
   switch (cfg) {
-    case CFG_128x128: return launch_one<128, 128, 2, 2, AM, BMD>(p, splits, s, fast);
-    case CFG_128x64: return launch_one<128, 64, 2, 2, AM, BMD>(p, splits, s, fast);
-    case CFG_64x64: return launch_one<64, 64, 2, 2, AM, BMD>(p, splits, s, fast);
-    case CFG_128x32: return launch_one<128, 32, 4, 1, AM, BMD>(p, splits, s, fast);
+    case CFG_128x128: return launch_one<128, 128, 2, 2, AM, BMD, 2>(p, splits, s, fast);
+    case CFG_128x64: return launch_one<128, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);
+    case CFG_64x64: return launch_one<64, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);
+    case CFG_128x32: return launch_one<128, 32, 4, 1, AM, BMD, 2>(p, splits, s, fast);
+    case CFG_128x128_S1:
+      return fast ? launch_one<128, 128, 2, 2, AM, BMD, 1>(p, splits, s, fast)
+                  : launch_one<128, 128, 2, 2, AM, BMD, 2>(p, splits, s, fast);
+    case CFG_128x64_S1:
+      return fast ? launch_one<128, 64, 2, 2, AM, BMD, 1>(p, splits, s, fast)
+                  : launch_one<128, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);
   }
   dj_set_error("bad tile cfg %d", cfg);
   return DJ_ERR_ARG;
@@ -123,6 +136,45 @@ static int choose_cfg(long M, long N, long K, bool allow_split, int* splits_out)
   *splits_out = splits;
   return cfg;
 }
+
+
+// ---------------------------------------------------------------------------------
+// Per-geometry launch overrides (tile configuration, split-K factor) recorded by the plan-time
+// autotuner (engine.Plan.autotune): key = direction (+4 when BN statistics are taken) + geometry.
+// ---------------------------------------------------------------------------------
+typedef std::array<int, 16> TuneKey;
+static std::map<TuneKey, std::pair<int, int>> g_tune;
+static std::mutex g_tune_mu;
+
+static TuneKey tune_key(int dir, const dj_conv2d_desc* d) {
+  return TuneKey{dir, d->batch, d->in_h, d->in_w, d->in_c, d->out_h, d->out_w, d->out_c, d->kernel_h, d->kernel_w,
+                 d->stride_h, d->stride_w, d->dilation_h, d->dilation_w, d->pad_top, d->pad_left};
+}
+
+static bool tune_lookup(int dir, const dj_conv2d_desc* d, int* cfg, int* splits) {
+  std::lock_guard<std::mutex> g(g_tune_mu);
+  auto it = g_tune.find(tune_key(dir, d));
+  if (it == g_tune.end()) return false;
+  *cfg = it->second.first;
+  *splits = it->second.second;
+  return true;
+}
+
+extern "C" int dj_conv2d_tune_configs(void) { return N_CFG; }
+
+// dir: 0 fwd, 1 dgrad, 2 wgrad, +4 when the forward takes BN statistics.  cfg < 0 removes the override.
+extern "C" int dj_conv2d_tune_set(int dir, const dj_conv2d_desc* d, int cfg, int splits) {
+  DJ_CHECK_ARG(d != nullptr && cfg < N_CFG && splits >= 1, "tune_set: bad arguments");
+  std::lock_guard<std::mutex> g(g_tune_mu);
+  if (cfg < 0)
+    g_tune.erase(tune_key(dir, d));
+  else
+    g_tune[tune_key(dir, d)] = std::make_pair(cfg, splits);
+  return DJ_OK;
+}
+
+// Default choice the launcher would make (for the tuner to seed its candidate list): writes cfg and splits.
+extern "C" int dj_conv2d_default_config(int dir, const dj_conv2d_desc* d, int* cfg, int* splits);
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
@@ -175,10 +227,8 @@ static void fill_geom(DjIgemmParams& p, const dj_conv2d_desc* d) {
 
 extern "C" int dj_conv2d_fwd_stats_rows(const dj_conv2d_desc* d) {
   if (check_desc(d) != DJ_OK) return DJ_ERR_ARG;
-  int splits;
-  long M = (long)d->batch * d->out_h * d->out_w;
-  int cfg = choose_cfg(M, d->out_c, (long)d->kernel_h * d->kernel_w * d->in_c, false, &splits);
-  return dj_cdiv(M, kCfgs[cfg].bm);
+  // one partial row per 64 output pixels, independent of the tile configuration the launcher picks
+  return dj_cdiv((long)d->batch * d->out_h * d->out_w, 64);
 }
 
 extern "C" int dj_conv2d_nhwc_fwd(const dj_conv2d_desc* d, const float* x, const float* w, const float* bias,
@@ -219,6 +269,8 @@ extern "C" int dj_conv2d_nhwc_fwd(const dj_conv2d_desc* d, const float* x, const
   p.b_bytes = extent_bytes((long)p.K, d->out_c, d->out_c);
   int splits = 1;
   int cfg = choose_cfg(p.M, p.N, p.K, stats == nullptr, &splits);
+  tune_lookup(stats ? 4 : 0, d, &cfg, &splits);
+  if (stats) splits = 1;
   p.kchunk = dj_cdiv(dj_cdiv(p.K, splits), DJ_BK) * DJ_BK;
   splits = dj_cdiv(p.K, p.kchunk);
   if (splits > 1) {
@@ -291,6 +343,7 @@ extern "C" int dj_conv2d_nhwc_dgrad(const dj_conv2d_desc* d, const float* dy, co
       }
     }
     int cfg = choose_cfg(p.M, p.N, p.K, false, &splits);
+    tune_lookup(1, d, &cfg, &splits);
     p.kchunk = dj_cdiv(p.K, DJ_BK) * DJ_BK;
     return launch_cfg<0, 1>(cfg, p, 1, s);
   }
@@ -303,6 +356,7 @@ extern "C" int dj_conv2d_nhwc_dgrad(const dj_conv2d_desc* d, const float* dy, co
   fill_geom(p, d);
   p.cmap = 0;
   int cfg = choose_cfg(p.M, p.N, p.K, true, &splits);
+  tune_lookup(1, d, &cfg, &splits);
   p.kchunk = dj_cdiv(dj_cdiv(p.K, splits), DJ_BK) * DJ_BK;
   splits = dj_cdiv(p.K, p.kchunk);
   if (splits > 1) {
@@ -368,6 +422,7 @@ extern "C" int dj_conv2d_nhwc_wgrad(const dj_conv2d_desc* d, const float* x, con
   if (maxs < 1) maxs = 1;
   splits = (int)(want < maxs ? want : maxs);
   if (splits < 1) splits = 1;
+  tune_lookup(2, d, &cfg, &splits);
   p.kchunk = dj_cdiv(dj_cdiv(p.K, splits), DJ_BK) * DJ_BK;
   splits = dj_cdiv(p.K, p.kchunk);
   if (splits > 1) {
@@ -379,4 +434,39 @@ extern "C" int dj_conv2d_nhwc_wgrad(const dj_conv2d_desc* d, const float* x, con
     }
   }
   return launch_cfg<2, 0>(cfg, p, splits, s);
+}
+
+extern "C" int dj_conv2d_default_config(int dir, const dj_conv2d_desc* d, int* cfg, int* splits) {
+  if (int rc = check_desc(d)) return rc;
+  DJ_CHECK_ARG(cfg && splits, "default_config: null output");
+  int base = dir & 3;
+  *splits = 1;
+  if (base == 0) {
+    *cfg = choose_cfg((long)d->batch * d->out_h * d->out_w, d->out_c, (long)d->kernel_h * d->kernel_w * d->in_c,
+                      (dir & 4) == 0, splits);
+  } else if (base == 1) {
+    bool strided_1x1 = d->kernel_h == 1 && d->kernel_w == 1 && d->pad_top == 0 && d->pad_left == 0 &&
+                       (d->stride_h > 1 || d->stride_w > 1) && d->stride_h == d->stride_w;
+    if (strided_1x1)
+      *cfg = choose_cfg((long)d->batch * d->out_h * d->out_w, d->in_c, d->out_c, false, splits);
+    else
+      *cfg = choose_cfg((long)d->batch * d->in_h * d->in_w, d->in_c, (long)d->kernel_h * d->kernel_w * d->out_c, true,
+                        splits);
+  } else {
+    long M = (long)d->kernel_h * d->kernel_w * d->in_c, N = d->out_c, K = (long)d->batch * d->out_h * d->out_w;
+    int c;
+    if (N > 96 && (long)dj_cdiv(N, 128) * 128 <= (long)dj_cdiv(N, 64) * 64)
+      c = (M >= 128) ? CFG_128x128 : CFG_64x64;
+    else if (N > 32)
+      c = (M >= 128) ? CFG_128x64 : CFG_64x64;
+    else
+      c = CFG_128x32;
+    long t = (long)dj_cdiv(M, kCfgs[c].bm) * dj_cdiv(N, kCfgs[c].bn);
+    long want = (768 + t - 1) / t, maxs = K / 128;
+    if (maxs < 1) maxs = 1;
+    *cfg = c;
+    *splits = (int)(want < maxs ? want : maxs);
+    if (*splits < 1) *splits = 1;
+  }
+  return DJ_OK;
 }

@@ -29,7 +29,7 @@ struct DjIgemmParams {
   const float* bias;       // [N] or null; added in the epilogue
   const float* pro_scale;  // [srcC] or null: A element -> A*scale[c] + shift[c] (in-bounds only)
   const float* pro_shift;
-  float* stats;            // [tiles_m][2][N] column sum / sum-of-squares of the raw accumulator, or null
+  float* stats;            // [ceil(M/64)][2][N] column sum / sum-of-squares of the raw accumulator per 64 rows, or null
   int M, N, K;
   int kchunk;              // K range handled per blockIdx.y (multiple of DJ_BK)
   // gather geometry
@@ -136,17 +136,22 @@ __device__ __forceinline__ void dj_igemm_epilogue(const DjIgemmParams& p, f32x16
       }
     }
     __syncthreads();
-    for (int col = tid; col < BN; col += 256) {
+    // one partial row per 64 GEMM rows, whatever the tile shape: [ceil(M/64)][2][N]
+    constexpr int GROUPS = BM / 64;          // 64-row groups in this tile
+    constexpr int WPG = WM / GROUPS;         // wave rows per group
+    for (int idx = tid; idx < GROUPS * BN; idx += 256) {
+      int g = idx / BN, col = idx - g * BN;
       float s = 0.f, q = 0.f;
 #pragma unroll
-      for (int w = 0; w < WM; ++w) {
-        s += red[(0 * WM + w) * BN + col];
-        q += red[(1 * WM + w) * BN + col];
+      for (int w = 0; w < WPG; ++w) {
+        s += red[(0 * WM + g * WPG + w) * BN + col];
+        q += red[(1 * WM + g * WPG + w) * BN + col];
       }
       int n = n0 + col;
-      if (n < p.N) {
-        p.stats[((size_t)tile_m * 2 + 0) * p.N + n] = s;
-        p.stats[((size_t)tile_m * 2 + 1) * p.N + n] = q;
+      if (n < p.N && m0 + 64 * g < p.M) {
+        size_t row = (size_t)(m0 / 64 + g);
+        p.stats[(row * 2 + 0) * p.N + n] = s;
+        p.stats[(row * 2 + 1) * p.N + n] = q;
       }
     }
   }

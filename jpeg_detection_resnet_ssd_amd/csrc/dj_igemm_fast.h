@@ -29,7 +29,7 @@ __device__ __forceinline__ f32x4 dj_buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned o
 }
 
 // PRO: 0 = plain A, 1 = A*scale[c]+shift[c] (then max(., floor) with floor = 0 or -inf) on in-bounds elements
-template <int BM, int BN, int WM, int WN, int AM, int BMD, int PRO>
+template <int BM, int BN, int WM, int WN, int AM, int BMD, int PRO, int NSTAGE = 2>
 __global__ __launch_bounds__(256) void dj_igemm_fast_kernel(const DjIgemmParams p) {
   using Cfg = DjIgemmCfg<BM, BN, WM, WN, AM, BMD>;
   constexpr int TM = Cfg::TM, TN = Cfg::TN, NA = Cfg::NA, NB = Cfg::NB;
@@ -306,12 +306,28 @@ __global__ __launch_bounds__(256) void dj_igemm_fast_kernel(const DjIgemmParams 
   transform();
   store_tiles(smem, smem + AFL);
   __syncthreads();
-  int kt = 0;
-  for (; kt + 1 < nk; kt += 2) {
-    kstep(std::integral_constant<int, 0>{}, kt);
-    kstep(std::integral_constant<int, 1>{}, kt + 1);
+  if (NSTAGE == 2) {
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      kstep(std::integral_constant<int, 0>{}, kt);
+      kstep(std::integral_constant<int, 1>{}, kt + 1);
+    }
+    if (kt < nk) kstep(std::integral_constant<int, 0>{}, kt);
+  } else {
+    // single LDS stage (half the LDS, twice the resident workgroups): the next tile waits in registers
+    // while this one is consumed; two barriers per K-step
+    for (int kt = 0; kt < nk; ++kt) {
+      issue_loads(kbeg + (kt + 1) * DJ_BK, kt + 1 < nk);
+      compute_kk(smem, smem + AFL, 0);
+      compute_kk(smem, smem + AFL, 1);
+      compute_kk(smem, smem + AFL, 2);
+      compute_kk(smem, smem + AFL, 3);
+      transform();
+      __syncthreads();
+      store_tiles(smem, smem + AFL);
+      __syncthreads();
+    }
   }
-  if (kt < nk) kstep(std::integral_constant<int, 0>{}, kt);
 
   dj_igemm_epilogue<BM, BN, WM, WN>(p, acc, smem, tile_m, m0, n0);
 }

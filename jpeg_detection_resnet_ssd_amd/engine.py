@@ -39,6 +39,9 @@ def query(name, *args):
     return check(getattr(_lib.load(), name)(*args), name)
 
 
+_TUNED = {}   # conv geometry key -> (ms, cfg, splits), process-wide
+
+
 class GradRef(object):
     """Gradient of a Value: a buffer, optionally to be masked by `mask_y > 0` by whoever reads it
     (lets Add+ReLU hand its upstream gradient to both branches without materialising the mask)."""
@@ -89,6 +92,7 @@ class Plan(object):
         self.bytes_allocated = 0
         self.hooks_after_backward = []
         self.grad_ready = {}   # weight key -> index in self.bwd after which its gradient is final
+        self.conv_calls = []   # (direction, ConvDesc, launch closure) of every implicit-GEMM call, for autotune()
 
     # ---- allocation -------------------------------------------------------------
     def empty(self, *shape):
@@ -107,6 +111,57 @@ class Plan(object):
 
     def emit_bwd(self, fn):
         self.bwd.append(fn)
+
+    def emit_conv(self, direction, desc, fn, backward=False):
+        """Record one implicit-GEMM launch (direction 0 fwd / 1 dgrad / 2 wgrad, +4 = forward with BN statistics)."""
+        (self.bwd if backward else self.fwd).append(fn)
+        self.conv_calls.append((direction, desc, fn))
+
+    def autotune(self, reps=2, verbose=False):
+        """Time every distinct conv geometry of this plan under each tile configuration / split-K factor on the
+        plan's own buffers and register the fastest with the launcher (dj_conv2d_tune_set).  Results only depend on
+        the geometry, so they are shared by all plans of the process."""
+        import ctypes
+        lib = _lib.load()
+        ncfg = lib.dj_conv2d_tune_configs()
+        names = [n for n, _ in _lib.ConvDesc._fields_][:15]
+        done = 0
+        for direction, desc, fn in self.conv_calls:
+            key = (direction,) + tuple(getattr(desc, n) for n in names)
+            if key in _TUNED:
+                continue
+            c0, s0 = ctypes.c_int(0), ctypes.c_int(1)
+            check(lib.dj_conv2d_default_config(direction, desc, ctypes.byref(c0), ctypes.byref(s0)), "default_config")
+            base = direction & 3
+            if direction & 4:
+                split_opts = [1]
+            elif base == 2:
+                kk = desc.batch * desc.out_h * desc.out_w
+                split_opts = sorted({1, max(1, s0.value // 2), s0.value, min(max(1, kk // 128), s0.value * 2)})
+            else:
+                split_opts = sorted({1, s0.value, 2, 4})
+            best = (float("inf"), c0.value, s0.value)
+            for cfg in range(ncfg):
+                for sp in split_opts:
+                    check(lib.dj_conv2d_tune_set(direction, desc, cfg, sp), "tune_set")
+                    fn()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(reps):
+                        fn()
+                    e1.record()
+                    e1.synchronize()
+                    t = e0.elapsed_time(e1) / reps
+                    if t < best[0]:
+                        best = (t, cfg, sp)
+            check(lib.dj_conv2d_tune_set(direction, desc, best[1], best[2]), "tune_set")
+            _TUNED[key] = best
+            done += 1
+            if verbose:
+                import sys
+                print("tuned dir=%d %s -> cfg %d splits %d (%.3f ms; default cfg %d splits %d)"
+                      % (direction, key[1:], best[1], best[2], best[0], c0.value, s0.value), file=sys.stderr)
+        return done
 
     def note_grad(self, spec):
         """Record that every launch writing `spec.grad` has been emitted (data-parallel bucketing)."""

@@ -264,7 +264,8 @@ class Conv2D(Layer):
             nrows = Kn.conv2d_stats_rows(desc)
             stats = plan.empty(nrows, 2, self.filters)
         xbuf = x.buf
-        plan.emit(lambda: Kn.conv2d_fwd(desc, xbuf, wgt, bias, y, pro[0], pro[1], pro[2], relu, stats))
+        plan.emit_conv(4 if stats is not None else 0, desc,
+                       lambda: Kn.conv2d_fwd(desc, xbuf, wgt, bias, y, pro[0], pro[1], pro[2], relu, stats))
         out = Value(y, needs_grad=True, name=self.name)
         if stats is not None:
             out.conv_stats = (stats, stats.shape[0], bias)
@@ -287,11 +288,11 @@ class Conv2D(Layer):
                     _bias_grad(plan, dy, self.bias)
             if self.kernel.trainable:
                 dw = self.kernel.grad
-                plan.emit_bwd(lambda: Kn.conv2d_wgrad(desc, xbuf, dy, dw, pro[0], pro[1], pro[2]))
+                plan.emit_conv(2, desc, lambda: Kn.conv2d_wgrad(desc, xbuf, dy, dw, pro[0], pro[1], pro[2]), backward=True)
                 plan.note_grad(self.kernel)
             if x.needs_grad:
                 dx, beta = plan.grad_of(x)
-                plan.emit_bwd(lambda: Kn.conv2d_dgrad(desc, dy, wgt, dx, None, bool(beta)))
+                plan.emit_conv(1, desc, lambda: Kn.conv2d_dgrad(desc, dy, wgt, dx, None, bool(beta)), backward=True)
 
         plan.on_backward(build_backward)
         return out
@@ -338,7 +339,7 @@ class Conv2DTranspose(Layer):
         assert (desc.out_h, desc.out_w) == (h, w)
         y = plan.empty(b, oh, ow, self.filters)
         wgt, bias = self.kernel.param, (self.bias.param if self.bias is not None else None)
-        plan.emit(lambda: Kn.conv2d_dgrad(desc, xbuf, wgt, y, bias, False))
+        plan.emit_conv(1, desc, lambda: Kn.conv2d_dgrad(desc, xbuf, wgt, y, bias, False))
         out = Value(y, needs_grad=True, name=self.name)
 
         def build_backward():
@@ -350,13 +351,13 @@ class Conv2DTranspose(Layer):
                 _bias_grad(plan, dy, self.bias)
             if self.kernel.trainable:
                 dw = self.kernel.grad
-                plan.emit_bwd(lambda: Kn.conv2d_wgrad(desc, dy, xbuf, dw))
+                plan.emit_conv(2, desc, lambda: Kn.conv2d_wgrad(desc, dy, xbuf, dw), backward=True)
                 plan.note_grad(self.kernel)
             if x.needs_grad:
                 dx, beta = plan.grad_of(x)
                 if beta:
                     raise NotImplementedError("accumulating Conv2DTranspose input gradient")
-                plan.emit_bwd(lambda: Kn.conv2d_fwd(desc, dy, wgt, None, dx))
+                plan.emit_conv(0, desc, lambda: Kn.conv2d_fwd(desc, dy, wgt, None, dx), backward=True)
 
         plan.on_backward(build_backward)
         return out

@@ -260,6 +260,9 @@ class Model(object):
             plan.on_backward(seed_gradient)
         if training:
             plan.build_backward()
+        if os.environ.get("DJ_AUTOTUNE", "1") != "0":
+            plan.autotune(verbose=os.environ.get("DJ_AUTOTUNE_VERBOSE", "0") == "1")
+        if training:
             if self.dist is not None and with_loss:
                 self.dist.attach(plan)
         self._plans[key] = plan
