@@ -565,78 +565,109 @@ extern "C" int dj_l2norm_bwd(const float* dy, int ld_dy, const float* x, int ldx
 }
 
 // ---------------------------------------------------------------------------------
-// MaxPooling2D((3,3), strides 1, 'same')  -- pool5_ssd
+// MaxPooling2D: k x k window, stride s, explicit leading pads.  pad_zero = 0: padding never wins (TF 'same'
+// / 'valid'); pad_zero = 1: out-of-range taps are zeros that take part in the max (a preceding ZeroPadding2D).
+// `pool5_ssd` is (3,3)/1/'same' (keras_ssd300_dct_j2d_resnet.py:481); the ResNet50RGB stem is ZeroPadding2D(1)
+// + (3,3)/2 (resnet_dct.py:165-314).
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dj_maxpool3x3s1_fwd_kernel(const float* x, float* y, int B, int H, int W,
-                                                                   int C) {
-  long total = (long)B * H * W * C;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int c = (int)(i % C);
-    long p = i / C;
-    int w = (int)(p % W);
-    long q = p / W;
-    int h = (int)(q % H);
-    int b = (int)(q / H);
-    float m = -INFINITY;
-    for (int dh = -1; dh <= 1; ++dh)
-      for (int dw = -1; dw <= 1; ++dw) {
-        int hh = h + dh, ww = w + dw;
-        if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W)
-          m = fmaxf(m, x[((long)(b * H + hh) * W + ww) * C + c]);
+struct PoolGeom {
+  int B, H, W, C, OH, OW, kh, kw, sh, sw, pt, pl, pad_zero;
+};
+
+__device__ __forceinline__ float pool_window(const float* x, const PoolGeom& g, int b, int oh, int ow, int c, int* ah,
+                                             int* aw) {
+  float m = -INFINITY;
+  int bh = -2, bw = -2;  // -2: nothing yet, -1: a zero pad tap won
+  for (int i = 0; i < g.kh; ++i)
+    for (int j = 0; j < g.kw; ++j) {
+      int hh = oh * g.sh + i - g.pt, ww = ow * g.sw + j - g.pl;
+      bool in = (unsigned)hh < (unsigned)g.H && (unsigned)ww < (unsigned)g.W;
+      if (!in && !g.pad_zero) continue;
+      float v = in ? x[((long)(b * g.H + hh) * g.W + ww) * g.C + c] : 0.f;
+      if (v > m) {  // first maximum in row-major window order
+        m = v;
+        bh = in ? hh : -1;
+        bw = in ? ww : -1;
       }
-    y[i] = m;
+    }
+  *ah = bh;
+  *aw = bw;
+  return m;
+}
+
+__global__ __launch_bounds__(256) void dj_maxpool2d_fwd_kernel(const float* x, float* y, PoolGeom g) {
+  long total = (long)g.B * g.OH * g.OW * g.C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % g.C);
+    long p = i / g.C;
+    int ow = (int)(p % g.OW);
+    long q = p / g.OW;
+    int oh = (int)(q % g.OH);
+    int b = (int)(q / g.OH);
+    int ah, aw;
+    y[i] = pool_window(x, g, b, oh, ow, c, &ah, &aw);
   }
 }
 
-// gradient goes to the first maximum of each window in row-major window order
-__global__ __launch_bounds__(256) void dj_maxpool3x3s1_bwd_kernel(const float* x, const float* dy, float* dx, int B,
-                                                                   int H, int W, int C, int beta) {
-  long total = (long)B * H * W * C;
+// gather form: each input element sums the gradients of the windows whose (first) maximum it is
+__global__ __launch_bounds__(256) void dj_maxpool2d_bwd_kernel(const float* x, const float* dy, float* dx, PoolGeom g,
+                                                                int beta) {
+  long total = (long)g.B * g.H * g.W * g.C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int c = (int)(i % C);
-    long p = i / C;
-    int w = (int)(p % W);
-    long q = p / W;
-    int h = (int)(q % H);
-    int b = (int)(q / H);
+    int c = (int)(i % g.C);
+    long p = i / g.C;
+    int w = (int)(p % g.W);
+    long q = p / g.W;
+    int h = (int)(q % g.H);
+    int b = (int)(q / g.H);
     float acc = 0.f;
-    // windows (centres) that contain (h, w)
-    for (int ch = h - 1; ch <= h + 1; ++ch)
-      for (int cw = w - 1; cw <= w + 1; ++cw) {
-        if ((unsigned)ch >= (unsigned)H || (unsigned)cw >= (unsigned)W) continue;
-        float m = -INFINITY;
-        int ah = -1, aw = -1;
-        for (int dh = -1; dh <= 1; ++dh)
-          for (int dw = -1; dw <= 1; ++dw) {
-            int hh = ch + dh, ww = cw + dw;
-            if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) {
-              float v = x[((long)(b * H + hh) * W + ww) * C + c];
-              if (v > m) {
-                m = v;
-                ah = hh;
-                aw = ww;
-              }
-            }
-          }
-        if (ah == h && aw == w) acc += dy[((long)(b * H + ch) * W + cw) * C + c];
+    // windows (oh, ow) with oh*sh - pt <= h < oh*sh - pt + kh
+    int oh_lo = (h + g.pt - g.kh + g.sh) / g.sh;  // ceil((h + pt - kh + 1) / sh)
+    if (h + g.pt - g.kh + 1 <= 0) oh_lo = 0;
+    int oh_hi = (h + g.pt) / g.sh;
+    int ow_lo = (w + g.pl - g.kw + g.sw) / g.sw;
+    if (w + g.pl - g.kw + 1 <= 0) ow_lo = 0;
+    int ow_hi = (w + g.pl) / g.sw;
+    if (oh_hi >= g.OH) oh_hi = g.OH - 1;
+    if (ow_hi >= g.OW) ow_hi = g.OW - 1;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh)
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        int ah, aw;
+        pool_window(x, g, b, oh, ow, c, &ah, &aw);
+        if (ah == h && aw == w) acc += dy[((long)(b * g.OH + oh) * g.OW + ow) * g.C + c];
       }
     dx[i] = beta ? dx[i] + acc : acc;
   }
 }
 
-extern "C" int dj_maxpool3x3s1_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) {
-  DJ_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && C > 0, "maxpool fwd: bad arguments");
-  hipLaunchKernelGGL(dj_maxpool3x3s1_fwd_kernel, dim3(ew_blocks((long)B * H * W * C)), dim3(256), 0,
-                     (hipStream_t)stream, x, y, B, H, W, C);
-  DJ_CHECK_LAUNCH("dj_maxpool3x3s1_fwd");
+static int pool_geom(PoolGeom* g, int B, int H, int W, int C, int OH, int OW, int kh, int kw, int sh, int sw, int pt,
+                     int pl, int pad_zero) {
+  DJ_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 && pt >= 0 &&
+                   pl >= 0,
+               "maxpool: bad geometry");
+  DJ_CHECK_ARG((long)(OH - 1) * sh - pt < H && (long)(OW - 1) * sw - pl < W, "maxpool: output grid too large");
+  *g = PoolGeom{B, H, W, C, OH, OW, kh, kw, sh, sw, pt, pl, pad_zero};
   return DJ_OK;
 }
 
-extern "C" int dj_maxpool3x3s1_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int beta,
-                                   void* stream) {
-  DJ_CHECK_ARG(x && dy && dx && B > 0 && H > 0 && W > 0 && C > 0, "maxpool bwd: bad arguments");
-  hipLaunchKernelGGL(dj_maxpool3x3s1_bwd_kernel, dim3(ew_blocks((long)B * H * W * C)), dim3(256), 0,
-                     (hipStream_t)stream, x, dy, dx, B, H, W, C, beta);
-  DJ_CHECK_LAUNCH("dj_maxpool3x3s1_bwd");
+extern "C" int dj_maxpool2d_fwd(const float* x, float* y, int B, int H, int W, int C, int OH, int OW, int kh, int kw,
+                                int sh, int sw, int pt, int pl, int pad_zero, void* stream) {
+  DJ_CHECK_ARG(x && y, "maxpool fwd: null tensor");
+  PoolGeom g;
+  if (int rc = pool_geom(&g, B, H, W, C, OH, OW, kh, kw, sh, sw, pt, pl, pad_zero)) return rc;
+  hipLaunchKernelGGL(dj_maxpool2d_fwd_kernel, dim3(ew_blocks((long)B * OH * OW * C)), dim3(256), 0, (hipStream_t)stream,
+                     x, y, g);
+  DJ_CHECK_LAUNCH("dj_maxpool2d_fwd");
+  return DJ_OK;
+}
+
+extern "C" int dj_maxpool2d_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int OH, int OW,
+                                int kh, int kw, int sh, int sw, int pt, int pl, int pad_zero, int beta, void* stream) {
+  DJ_CHECK_ARG(x && dy && dx, "maxpool bwd: null tensor");
+  PoolGeom g;
+  if (int rc = pool_geom(&g, B, H, W, C, OH, OW, kh, kw, sh, sw, pt, pl, pad_zero)) return rc;
+  hipLaunchKernelGGL(dj_maxpool2d_bwd_kernel, dim3(ew_blocks((long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, x,
+                     dy, dx, g, beta);
+  DJ_CHECK_LAUNCH("dj_maxpool2d_bwd");
   return DJ_OK;
 }

@@ -187,13 +187,24 @@ def Input(shape=None, batch_shape=None, name=None, dtype=None, tensor=None):
 # =====================================================================================
 # helpers shared by the lowerings
 # =====================================================================================
-def _materialised(v, who):
-    if v.is_affine:
-        raise NotImplementedError("%s cannot consume a virtual BatchNormalization output; "
-                                  "this graph shape is outside the reference's builders" % who)
-    if v.pad is not None:
+def _materialised(v, who, plan=None, allow_pad=False):
+    """Buffer holding the value itself.  A virtual BatchNormalization(+ReLU) output is written out with one
+    dj_affine_act pass (cached per Value); gradients keep being requested on `v`, whose BatchNormalization applies
+    the ReLU mask itself."""
+    if v.pad is not None and not allow_pad:
         raise NotImplementedError("%s cannot consume a pending ZeroPadding2D" % who)
-    return v.buf
+    if not v.is_affine:
+        return v.buf
+    if plan is None:
+        raise NotImplementedError("%s cannot consume a virtual BatchNormalization output" % who)
+    src = v.alias_of if (v.alias_of is not None and v.pad is not None) else v   # ZeroPadding2D alias shares the data
+    if getattr(src, "_mat", None) is None:
+        rows, c, ld = rows_of(src.buf)
+        y = plan.empty(*src.buf.shape)
+        zbuf, sc, sh, relu = src.buf, src.scale, src.shift, int(src.relu)
+        plan.emit(lambda: call("dj_affine_act", zbuf, ld, sc, sh, None, 0, None, None, y, c, rows, c, relu))
+        src._mat = y
+    return src._mat
 
 
 def _bias_grad(plan, dy, spec):
@@ -330,7 +341,7 @@ class Conv2DTranspose(Layer):
 
     def lower(self, plan, model, ins):
         x = ins[0]
-        xbuf = _materialised(x, self.name)
+        xbuf = _materialised(x, self.name, plan)
         b, h, w, cin = xbuf.shape
         oh = (h - 1) * self.strides[0] + self.kernel_size[0]
         ow = (w - 1) * self.strides[1] + self.kernel_size[1]
@@ -389,7 +400,7 @@ class Dense(Layer):
 
     def lower(self, plan, model, ins):
         x = ins[0]
-        xbuf = _materialised(x, self.name)
+        xbuf = _materialised(x, self.name, plan)
         assert xbuf.dim() == 2
         b, cin = xbuf.shape
         desc = Kn.make_conv_desc(b, 1, 1, cin, self.units, (1, 1))
@@ -431,7 +442,7 @@ class Dense(Layer):
 
 
 def _lower_softmax(plan, x, name):
-    xbuf = _materialised(x, name)
+    xbuf = _materialised(x, name, plan)
     c = xbuf.shape[-1]
     rows = xbuf.numel() // c
     assert xbuf.is_contiguous()
@@ -479,7 +490,7 @@ class BatchNormalization(Layer):
 
     def lower(self, plan, model, ins):
         x = ins[0]
-        z = _materialised(x, self.name)
+        z = _materialised(x, self.name, plan)
         rows, c, ld = rows_of(z)
         scale, shift = plan.empty(c), plan.empty(c)
         gamma, beta = self.gamma.param, self.beta.param
@@ -558,7 +569,7 @@ class Activation(Layer):
             v = Value(x.buf, scale=x.scale, shift=x.shift, relu=True, needs_grad=x.needs_grad, name=self.name)
             x.relu_child = v
             return v
-        xbuf = _materialised(x, self.name)
+        xbuf = _materialised(x, self.name, plan)
         rows, c, ld = rows_of(xbuf)
         y = plan.empty(*xbuf.shape)
         plan.emit(lambda: call("dj_affine_act", xbuf, ld, None, None, None, 0, None, None, y, c, rows, c, 1))
@@ -645,7 +656,7 @@ class Concatenate(Layer):
         return tuple(out)
 
     def lower(self, plan, model, ins):
-        bufs = [_materialised(v, self.name) for v in ins]
+        bufs = [_materialised(v, self.name, plan) for v in ins]
         nd = bufs[0].dim()
         ax = self.axis % nd
         assert ax >= 1
@@ -717,7 +728,7 @@ class Reshape(Layer):
 
     def lower(self, plan, model, ins):
         x = ins[0]
-        xbuf = _materialised(x, self.name)
+        xbuf = _materialised(x, self.name, plan)
         assert xbuf.is_contiguous()
         shape = (xbuf.shape[0],) + tuple(self.output_shape[1:])
         out = Value(xbuf.view(*shape), needs_grad=x.needs_grad, name=self.name)
@@ -771,14 +782,20 @@ class MaxPooling2D(Layer):
         return (b, oh, ow, c)
 
     def lower(self, plan, model, ins):
-        if not (self.pool_size == (3, 3) and self.strides == (1, 1) and self.padding == "same"):
-            raise NotImplementedError("MaxPooling2D other than pool5_ssd's (3,3)/1/'same'")
         x = ins[0]
-        xbuf = _materialised(x, self.name)
+        xbuf = _materialised(x, self.name, plan, allow_pad=True)
         assert xbuf.is_contiguous()
         b, h, w, c = xbuf.shape
-        y = plan.empty(b, h, w, c)
-        plan.emit(lambda: call("dj_maxpool3x3s1_fwd", xbuf, y, b, h, w, c))
+        padding, pad_zero = self.padding, 0
+        if x.pad is not None:   # ZeroPadding2D in front: zeros take part in the max
+            if padding != "valid":
+                raise NotImplementedError("ZeroPadding2D followed by a 'same' MaxPooling2D")
+            padding, pad_zero = x.pad, 1
+        pt, pl, oh, ow = Kn.conv_geometry(h, w, self.pool_size, self.strides, padding, (1, 1))
+        kh, kw = self.pool_size
+        sh, sw = self.strides
+        y = plan.empty(b, oh, ow, c)
+        plan.emit(lambda: call("dj_maxpool2d_fwd", xbuf, y, b, h, w, c, oh, ow, kh, kw, sh, sw, pt, pl, pad_zero))
         out = Value(y, needs_grad=x.needs_grad, name=self.name)
 
         def build_backward():
@@ -787,7 +804,8 @@ class MaxPooling2D(Layer):
             dy = out.grad.buf
             dx, beta = plan.grad_of(x)
             assert dx.is_contiguous() and dy.is_contiguous()
-            plan.emit_bwd(lambda: call("dj_maxpool3x3s1_bwd", xbuf, dy, dx, b, h, w, c, beta))
+            plan.emit_bwd(lambda: call("dj_maxpool2d_bwd", xbuf, dy, dx, b, h, w, c, oh, ow, kh, kw, sh, sw, pt, pl,
+                                       pad_zero, beta))
 
         plan.on_backward(build_backward)
         return out
@@ -806,7 +824,7 @@ class UpSampling2D(Layer):
 
     def lower(self, plan, model, ins):
         x = ins[0]
-        xbuf = _materialised(x, self.name)
+        xbuf = _materialised(x, self.name, plan)
         if x.needs_grad:
             raise NotImplementedError("UpSampling2D gradient (the reference only up-samples model inputs)")
         b, h, w, c = xbuf.shape
@@ -821,7 +839,7 @@ class GlobalAveragePooling2D(Layer):
 
     def lower(self, plan, model, ins):
         x = ins[0]
-        xbuf = _materialised(x, self.name)
+        xbuf = _materialised(x, self.name, plan)
         assert xbuf.is_contiguous()
         b, h, w, c = xbuf.shape
         y = plan.empty(b, c)

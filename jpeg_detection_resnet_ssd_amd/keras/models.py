@@ -358,12 +358,32 @@ class Model(object):
         self.last_step_info = dict(data_loss=data, reg_loss=reg, n_positive=float(vals[1]), n_negative=float(vals[2]))
         return data + reg
 
+    def _metric_values(self, plan):
+        """Compile-time `metrics` callables, evaluated as metric(y_true, y_pred) on the device-resident batch;
+        named like Keras names anonymous metric functions (`_func`, `_func_1`, ...)."""
+        out, seen = {}, {}
+        for m in self.metrics:
+            name = getattr(m, "__name__", str(m)) if callable(m) else str(m)
+            if not callable(m):
+                if name in ("accuracy", "acc"):
+                    from .metrics import categorical_accuracy as m
+                    name = "acc"
+                else:
+                    continue
+            n = seen.get(name, 0)
+            seen[name] = n + 1
+            out[name if n == 0 else "%s_%d" % (name, n)] = float(m(plan.y_true, plan.outputs[0].buf))
+        return out
+
     def train_on_batch(self, x, y):
         b = self._as_list(x)[0].shape[0]
         plan = self._plan(b, True, True)
         self._upload(plan, x, y)
         self.run_train_step(plan)
-        return self._loss_value(plan)
+        loss = self._loss_value(plan)
+        if self.metrics:
+            self.last_step_info["metrics"] = self._metric_values(plan)
+        return loss
 
     def test_on_batch(self, x, y):
         b = self._as_list(x)[0].shape[0]
@@ -409,6 +429,7 @@ class Model(object):
         cb_list = [history] + list(callbacks or [])
         for cb in cb_list:
             cb.set_model(self)
+            cb.params = {"steps": steps_per_epoch, "epochs": epochs}
             cb.on_train_begin()
         it = iter(generator)
         val_it = iter(validation_data) if validation_data is not None and not isinstance(validation_data, tuple) else None
@@ -417,18 +438,25 @@ class Model(object):
         for epoch in range(initial_epoch, epochs):
             for cb in cb_list:
                 cb.on_epoch_begin(epoch)
-            t0, run = time.time(), 0.0
+            t0, run, run_metrics = time.time(), 0.0, {}
             for step in range(steps_per_epoch):
+                for cb in cb_list:
+                    cb.on_batch_begin(step)
                 batch = next(it)
                 x, y = batch[0], batch[1]
                 loss = self.train_on_batch(x, y)
                 run += loss
                 logs = {"loss": loss, "batch": step, "size": self._as_list(x)[0].shape[0]}
+                for mk, mv in self.last_step_info.get("metrics", {}).items():
+                    logs[mk] = mv
+                    run_metrics[mk] = run_metrics.get(mk, 0.0) + mv
                 for cb in cb_list:
                     cb.on_batch_end(step, logs)
                 if self.stop_training:
                     break
             logs = {"loss": run / max(1, step + 1), "lr": self.optimizer.current_lr()}
+            for mk, mv in run_metrics.items():
+                logs[mk] = mv / max(1, step + 1)
             if validation_data is not None:
                 vl, nv = 0.0, 0
                 if val_it is not None:

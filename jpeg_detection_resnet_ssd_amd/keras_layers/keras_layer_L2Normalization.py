@@ -31,7 +31,7 @@ class L2Normalization(Layer):
 
     def lower(self, plan, model, ins):
         x = ins[0]
-        xbuf = _materialised(x, self.name)
+        xbuf = _materialised(x, self.name, plan)
         rows, c, ldx = rows_of(xbuf)
         y = plan.empty(*xbuf.shape)
         rnorm = plan.empty(rows)

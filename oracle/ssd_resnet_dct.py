@@ -275,3 +275,50 @@ def ssd_training_step(weights, inputs, y_true, archi, lr=0.001, momentum=0.9, de
     new_w.update(net.new_state)
     return dict(loss=float(loss.detach()), data_loss=float(data_loss.detach()), reg_loss=float(reg.detach()), y_pred=y_pred.detach(),
                 grads=grads, new_weights=new_w, new_velocities=new_v, net=net)
+
+
+def resnet_rgb_forward(weights, image, training=True):
+    """ResNet50RGB (C/vgg_jpeg_keras/networks/resnet_dct.py:165-314): -> (probs, net).  `image` (B,224,224,3)."""
+    net = Net(weights, training)
+    x = ko.zero_padding(image, ((3, 3), (3, 3)))
+    x = ko.relu(net.bn(net.conv(x, "conv1", strides=(2, 2)), "bn_conv1"))
+    x = ko.max_pool(ko.zero_padding(x, ((1, 1), (1, 1))), (3, 3), (2, 2), "valid")
+    x = net.conv_block(x, 3, 2, "a", (1, 1))
+    for b in "bc":
+        x = net.identity_block(x, 3, 2, b)
+    x = net.conv_block(x, 3, 3, "a")
+    for b in "bcd":
+        x = net.identity_block(x, 3, 3, b)
+    x = net.conv_block(x, 3, 4, "a")
+    for b in "bcdef":
+        x = net.identity_block(x, 3, 4, b)
+    x = _block5(net, x)
+    x = ko.global_average_pooling(x)
+    return ko.softmax(ko.dense(x, weights["fc1000/kernel"], weights["fc1000/bias"])), net
+
+
+def classifier_training_step(weights, inputs, y_onehot, archi, lr=0.1, momentum=0.9, decay=1e-4, nesterov=True,
+                             velocities=None, iterations=0):
+    """One train_on_batch of the classification trainer (C/training.py:175-198, C/config/resnet/config_file.py:58-65):
+    categorical cross-entropy (batch mean) + Keras SGD.  archi 'resnet_rgb' or a DCT archi name."""
+    leaf = {}
+    for k, v in weights.items():
+        is_state = k.endswith("moving_mean") or k.endswith("moving_variance")
+        leaf[k] = v.clone().requires_grad_(not is_state)
+    if archi == "resnet_rgb":
+        probs, net = resnet_rgb_forward(leaf, inputs[0], training=True)
+    else:
+        probs, net = classifier_forward(leaf, inputs, archi, training=True)
+    loss = ko.categorical_crossentropy(y_onehot, probs).mean()
+    loss.backward()
+    new_w, new_v, grads = {}, {}, {}
+    for k, v in leaf.items():
+        if v.requires_grad and v.grad is not None:
+            grads[k] = v.grad.detach()
+            vel = velocities[k] if velocities is not None else torch.zeros_like(v)
+            p, nv = ko.sgd_keras_step(v.detach(), v.grad, vel, lr, momentum, decay, iterations, nesterov)
+            new_w[k], new_v[k] = p, nv
+        else:
+            new_w[k] = v.detach()
+    new_w.update(net.new_state)
+    return dict(loss=float(loss.detach()), probs=probs.detach(), grads=grads, new_weights=new_w, new_velocities=new_v)

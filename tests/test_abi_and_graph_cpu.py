@@ -133,3 +133,69 @@ def test_synthetic_dct_follows_jpeg2dct_semantics():
     flat = np.full((300, 300, 3), 200, np.uint8)
     yf, cbf, crf = sd.rgb_to_dct(flat)
     assert yf[0, 0, 0] == np.round((200 - 128) * 8 / 8) * 8 and np.all(yf[..., 1:] == 0) and np.all(cbf == 0)
+
+
+@pytest.mark.parametrize("archi,params,inputs", [
+    ("resnet_rgb", 25636712, [(None, 224, 224, 3)]),
+    ("deconv", 28434280, [(None, 28, 28, 64), (None, 14, 14, 64), (None, 14, 14, 64)]),
+    ("late_concat_rfa_thinner", 28726632, [(None, 28, 28, 64), (None, 14, 14, 128)]),
+    ("up_sampling_rfa", 28401384, [(None, 28, 28, 64), (None, 14, 14, 128)]),
+    ("up_sampling", None, None), ("cb5_only", None, None), ("late_concat_more_channels", None, None),
+    ("y_cb4_cbcr_cb5", None, None)])
+def test_classifier_graph_structure(archi, params, inputs):
+    """ResNet50RGB has the stock Keras ResNet50 parameter count; the DCT archis match SURVEY 8(d)."""
+    from jpeg_detection_resnet_ssd_amd.keras import backend as K
+    from jpeg_detection_resnet_ssd_amd.vgg_jpeg_keras.networks.resnet_dct import ResNet50Custom, ResNet50RGB
+    K.clear_session()
+    m = ResNet50RGB(weights=None, archi="ignored") if archi == "resnet_rgb" else ResNet50Custom(weights=None, archi=archi)
+    assert m.outputs[0].shape == (None, 1000)
+    if params:
+        assert m.count_params() == params
+        assert [t.shape for t in m.inputs] == inputs
+    names = [l.name for l in m.layers]
+    assert "avg_pool" in names and "fc1000" in names and "res5c_branch2c" in names
+    if archi == "resnet_rgb":
+        assert names[:6] == ["input_1", "conv1_pad", "conv1", "bn_conv1", "activation_1", "pool1_pad"]
+    with pytest.raises(RuntimeError, match="no network"):
+        ResNet50Custom(weights="imagenet", archi="deconv")
+    with pytest.raises(ValueError):
+        ResNet50Custom(weights=None, archi="bogus")
+
+
+def test_classification_config_and_horovod_scaling_rules():
+    """TrainingConfiguration surface + the reference's Horovod scaling rules (config/resnet/config_file.py:121-150)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("cfg_resnet", os.path.join(ROOT, "config", "resnet", "config_file.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    from jpeg_detection_resnet_ssd_amd.keras import backend as K
+    K.clear_session()
+    cfg = mod.TrainingConfiguration(deconv=True, archi="deconv", load_pretrained_weights=False)
+    assert (cfg.batch_size, cfg.steps_per_epoch, cfg.epochs, cfg.validation_steps) == (256, 5000, 120, 195)
+    assert cfg.optimizer.get_config() == {"lr": 0.1, "momentum": 0.9, "decay": 0.0001, "nesterov": True}
+    assert len(cfg.metrics) == 2 and cfg.network.count_params() == 28434280
+
+    class FakeHvd:
+        class callbacks:
+            BroadcastGlobalVariablesCallback = staticmethod(lambda r: ("bcast", r))
+            MetricAverageCallback = staticmethod(lambda: "avg")
+            LearningRateWarmupCallback = staticmethod(lambda warmup_epochs, verbose: ("warmup", warmup_epochs))
+
+        @staticmethod
+        def size():
+            return 16
+
+        @staticmethod
+        def rank():
+            return 0
+
+        @staticmethod
+        def DistributedOptimizer(o):
+            return o
+    cfg.prepare_horovod(FakeHvd)
+    assert abs(cfg.optimizer.lr - 0.1 * 16 / 4) < 1e-12            # lr * size / batch_size_divider
+    assert cfg.batch_size == 64 and cfg.steps_per_epoch == 5000 // 4 and cfg.validation_steps == 3 * 195 // 16
+    assert cfg.callbacks[0] == ("bcast", 0) and cfg.callbacks[2] == ("warmup", 5)
+    cfg.prepare_training_generators()
+    x, y = cfg.train_generator[0]
+    assert [a.shape for a in x] == [(64, 28, 28, 64), (64, 14, 14, 64), (64, 14, 14, 64)] and y.shape == (64, 1000)

@@ -141,11 +141,29 @@ def test_maxpool(hw, cuda, E):
     yr = ko.max_pool_3x3_s1_same(xr)
     yr.backward(dy.double())
     y, dx = torch.empty(x.shape, device=cuda), torch.empty(x.shape, device=cuda)
-    E.call("dj_maxpool3x3s1_fwd", x.to(cuda), y, 3, hw, hw, 256)
-    E.call("dj_maxpool3x3s1_bwd", x.to(cuda), dy.to(cuda), dx, 3, hw, hw, 256, 0)
+    E.call("dj_maxpool2d_fwd", x.to(cuda), y, 3, hw, hw, 256, hw, hw, 3, 3, 1, 1, 1, 1, 0)
+    E.call("dj_maxpool2d_bwd", x.to(cuda), dy.to(cuda), dx, 3, hw, hw, 256, hw, hw, 3, 3, 1, 1, 1, 1, 0, 0)
     torch.cuda.synchronize()
     assert torch.equal(y.cpu().double(), yr.detach())
     assert close(dx, xr.grad, rel=1e-5)
+
+
+def test_maxpool_stem_zero_padded_stride2(cuda, E):
+    """ZeroPadding2D(1) + MaxPooling2D((3,3), strides 2): the ResNet50RGB stem (zeros take part in the max)."""
+    g = torch.Generator().manual_seed(19)
+    b, hw, c = 2, 12, 64
+    x = torch.randn(b, hw, hw, c, generator=g)        # negative values: a zero pad can win
+    xr = x.double().requires_grad_(True)
+    yr = ko.max_pool(ko.zero_padding(xr, ((1, 1), (1, 1))), (3, 3), (2, 2), "valid")
+    oh = yr.shape[1]
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+    y, dx = torch.empty(yr.shape, device=cuda), torch.ones(x.shape, device=cuda)
+    E.call("dj_maxpool2d_fwd", x.to(cuda), y, b, hw, hw, c, oh, oh, 3, 3, 2, 2, 1, 1, 1)
+    E.call("dj_maxpool2d_bwd", x.to(cuda), dy.to(cuda), dx, b, hw, hw, c, oh, oh, 3, 3, 2, 2, 1, 1, 1, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu().double(), yr.detach())
+    assert close(dx - 1.0, xr.grad, rel=1e-5)
 
 
 @pytest.mark.parametrize("rows,c", [(5000, 21), (64, 1000)])
