@@ -130,7 +130,7 @@ def main():
     model, sizes = workloads.build_ssd(args.archi)
     model._ensure_params()
     dp = None
-    if world > 1:
+    if torch.distributed.is_initialized():
         dp = djdist.DataParallel(model)
         dp.broadcast_weights(0)
     # rank r draws its own shard of the global batch (data seed 1234 + r)
@@ -140,7 +140,7 @@ def main():
     torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if torch.distributed.is_initialized():
             torch.distributed.barrier()
 
     for _ in range(args.warmup):
@@ -196,3 +196,6 @@ def main():
 
 if __name__ == "__main__":
     main()
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()

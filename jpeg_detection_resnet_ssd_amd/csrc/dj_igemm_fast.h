@@ -42,9 +42,19 @@ __global__ __launch_bounds__(256) void dj_igemm_fast_kernel(const DjIgemmParams 
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lh = lane >> 5;
 
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blockIdx.x % 8 labels the XCD group),
+  // each XCD has its own L2.  Give every XCD a CONTIGUOUS run of the tile list (column tiles of one row tile are
+  // adjacent), so the A rows shared by those column tiles are fetched into one L2 instead of eight.  Bijective for
+  // any grid size; placement only affects speed.
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int tile_m = blockIdx.x / tiles_n;
-  const int tile_n = blockIdx.x - tile_m * tiles_n;
+  int tile_id;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, slot = b >> 3;
+    tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int tile_m = tile_id / tiles_n;
+  const int tile_n = tile_id - tile_m * tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int kbeg = blockIdx.y * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);

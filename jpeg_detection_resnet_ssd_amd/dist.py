@@ -25,7 +25,8 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("DJ_FORCE_DIST", "0") == "1"   # exercise the RCCL path on a 1-rank communicator
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -99,12 +100,12 @@ class DataParallel(object):
 
     def broadcast_weights(self, src=0):
         """Rank `src`'s weights (trainable and BatchNormalization state) to every rank."""
-        if self.world > 1:
+        if dist.is_initialized():
             dist.broadcast(self.model.flat_all, src=src)
 
     def attach(self, plan):
         """Insert the bucketed all-reduces into the plan's backward launch list."""
-        if self.world == 1 or id(plan) in self._attached:
+        if not dist.is_initialized() or id(plan) in self._attached:
             return
         m = self.model
         if self.exchange is None:
@@ -123,7 +124,7 @@ class DataParallel(object):
         self.n_buckets = len(buckets)
 
     def finish_gradients(self):
-        if self.world == 1 or self.exchange is None:
+        if self.exchange is None:
             return 1.0
         return self.exchange.finish()
 
