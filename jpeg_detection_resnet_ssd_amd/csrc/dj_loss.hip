@@ -80,9 +80,9 @@ extern "C" int dj_softmax_bwd(const float* p, const float* dp, long ld_dp, float
 __global__ __launch_bounds__(256) void dj_ssd_loss_boxes_kernel(const float* y_true, const float* y_pred, long nbox,
                                                                  int n_cls, float* cls, float* loc, float* pos,
                                                                  float* negloss, float* partial) {
-  __shared__ float red[3][256];
+  __shared__ float red[4][256];
   const int W = n_cls + 12;
-  float s_pos = 0.f, s_pc = 0.f, s_pl = 0.f;
+  float s_pos = 0.f, s_pc = 0.f, s_pl = 0.f, s_nz = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nbox; i += (long)gridDim.x * blockDim.x) {
     const float* t = y_true + i * W;
     const float* p = y_pred + i * W;
@@ -102,6 +102,7 @@ __global__ __launch_bounds__(256) void dj_ssd_loss_boxes_kernel(const float* y_t
     loc[i] = lo;
     pos[i] = pmax;
     negloss[i] = cl * t[0];
+    s_nz += (cl * t[0] != 0.f) ? 1.f : 0.f;
     s_pos += pmax;
     s_pc += cl * pmax;
     s_pl += lo * pmax;
@@ -109,139 +110,201 @@ __global__ __launch_bounds__(256) void dj_ssd_loss_boxes_kernel(const float* y_t
   red[0][threadIdx.x] = s_pos;
   red[1][threadIdx.x] = s_pc;
   red[2][threadIdx.x] = s_pl;
+  red[3][threadIdx.x] = s_nz;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if (threadIdx.x < o) {
       red[0][threadIdx.x] += red[0][threadIdx.x + o];
       red[1][threadIdx.x] += red[1][threadIdx.x + o];
       red[2][threadIdx.x] += red[2][threadIdx.x + o];
+      red[3][threadIdx.x] += red[3][threadIdx.x + o];
     }
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    partial[blockIdx.x * 3 + 0] = red[0][0];
-    partial[blockIdx.x * 3 + 1] = red[1][0];
-    partial[blockIdx.x * 3 + 2] = red[2][0];
+    partial[blockIdx.x * 4 + 0] = red[0][0];
+    partial[blockIdx.x * 4 + 1] = red[1][0];
+    partial[blockIdx.x * 4 + 2] = red[2][0];
+    partial[blockIdx.x * 4 + 3] = red[3][0];
   }
 }
 
-#define DJ_MINE_THREADS 1024
+// ---- batch-wide hard-negative mining: exact k-th largest negative loss by a 3-level radix select (11+11+10
+// bits of the fp32 pattern; losses are >= 0 so the patterns order like unsigned ints), spread over many workgroups.
+// Every workgroup re-derives the selection state from the small global histograms, so no host round trip and no
+// single-block pass over the batch is needed.  Ties at the threshold are resolved by arrival order (tf.nn.top_k
+// leaves tie order unspecified as well).
+#define DJ_HB 2048
+struct MineState {
+  long k;          // negatives to keep
+  unsigned prefix; // selected high bits so far
+  long need;       // how many still to take from the current prefix class
+  double npos, spc, spl;
+};
 
-// block-wide exclusive prefix sum of one int per thread (1024 threads = 16 waves)
-__device__ __forceinline__ int block_excl_scan(int v, int* wsum, int* total) {
-  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int incl = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    int t = __shfl_up(incl, o);
-    if (lane >= o) incl += t;
-  }
-  if (lane == 63) wsum[wave] = incl;
+__device__ __forceinline__ void mine_reduce_partials(const float* partial, int npartial, double* out4) {
+  __shared__ double red4[4][256];
+  double a[4] = {0, 0, 0, 0};
+  for (int b = threadIdx.x; b < npartial; b += blockDim.x)
+    for (int q = 0; q < 4; ++q) a[q] += (double)partial[b * 4 + q];
+  for (int q = 0; q < 4; ++q) red4[q][threadIdx.x] = a[q];
   __syncthreads();
-  int base = 0, tot = 0;
-  for (int w = 0; w < DJ_MINE_THREADS / 64; ++w) {
-    int t = wsum[w];
-    if (w < wave) base += t;
-    tot += t;
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o)
+      for (int q = 0; q < 4; ++q) red4[q][threadIdx.x] += red4[q][threadIdx.x + o];
+    __syncthreads();
   }
+  for (int q = 0; q < 4; ++q) out4[q] = red4[q][0];
   __syncthreads();
-  *total = tot;
-  return base + incl - v;
 }
 
-__global__ __launch_bounds__(DJ_MINE_THREADS) void dj_ssd_loss_mine_kernel(
-    const float* cls, const float* negloss, long nbox, const float* partial, int npartial, int neg_pos_ratio,
-    int n_neg_min, float alpha, float* keep, float* out) {
-  __shared__ unsigned hist[256];
-  __shared__ int wsum[DJ_MINE_THREADS / 64];
-  __shared__ double dred[3];
-  __shared__ unsigned s_prefix;
-  __shared__ long s_k;
+// scan one histogram level from the top: find the bin where the cumulative count reaches `need`
+// (256 threads: LDS copy, per-thread run of nbins/256 bins, Hillis-Steele scan over the runs)
+__device__ __forceinline__ void mine_scan_level(const unsigned* hist, int nbins, long need, int* bin_out, long* need_out) {
+  __shared__ unsigned sh[DJ_HB];
+  __shared__ long cum[256];
+  __shared__ int s_bin;
   __shared__ long s_need;
-  __shared__ float s_keepsum[DJ_MINE_THREADS / 64];
-  const int tid = threadIdx.x;
-  if (tid < 3) {
-    double s = 0.0;
-    for (int b = 0; b < npartial; ++b) s += (double)partial[b * 3 + tid];
-    dred[tid] = s;
-  }
-  // number of non-zero negative losses
-  int cnt = 0;
-  for (long i = tid; i < nbox; i += DJ_MINE_THREADS) cnt += (negloss[i] != 0.f);
-  int total_nz;
-  block_excl_scan(cnt, wsum, &total_nz);
-  if (tid == 0) {
-    long npos = (long)dred[0];  // tf.to_int32 truncation of the float sum
-    long k = (long)neg_pos_ratio * npos;
-    if (k < n_neg_min) k = n_neg_min;
-    if (k > total_nz) k = total_nz;
-    s_k = k;
-    s_prefix = 0u;
-    s_need = k;
+  const int t = threadIdx.x;
+  const int per = nbins / 256;
+  for (int j = t; j < nbins; j += 256) sh[j] = hist[j];
+  if (t == 0) {
+    s_bin = 0;
+    s_need = need;
   }
   __syncthreads();
-  const long k = s_k;
-  // radix select (descending) of the k-th largest value; negloss >= 0 so float bits order as unsigned
+  long local = 0;
+  for (int e = 0; e < per; ++e) local += sh[nbins - 1 - (t * per + e)];
+  cum[t] = local;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    long v = (t >= off) ? cum[t - off] : 0;
+    __syncthreads();
+    cum[t] += v;
+    __syncthreads();
+  }
+  long before = (t > 0) ? cum[t - 1] : 0;
+  if (cum[t] >= need && before < need) {
+    long rem = need - before;
+    for (int e = 0; e < per; ++e) {
+      int idx = nbins - 1 - (t * per + e);
+      long h = sh[idx];
+      if (h >= rem) {
+        s_bin = idx;
+        s_need = rem;
+        break;
+      }
+      rem -= h;
+    }
+  }
+  __syncthreads();
+  *bin_out = s_bin;
+  *need_out = s_need;
+  __syncthreads();
+}
+
+__device__ __forceinline__ MineState mine_state(const float* partial, int npartial, const unsigned* hist, int level,
+                                                int ratio, int nmin) {
+  double t[4];
+  mine_reduce_partials(partial, npartial, t);
+  MineState st;
+  st.npos = t[0];
+  st.spc = t[1];
+  st.spl = t[2];
+  long k = (long)ratio * (long)t[0];
+  if (k < nmin) k = nmin;
+  long nnz = (long)t[3];
+  if (k > nnz) k = nnz;
+  st.k = k;
+  st.prefix = 0u;
+  st.need = k;
   if (k > 0) {
-    for (int shift = 24; shift >= 0; shift -= 8) {
-      for (int j = tid; j < 256; j += DJ_MINE_THREADS) hist[j] = 0u;
-      __syncthreads();
-      unsigned prefix = s_prefix;
-      unsigned himask = (shift == 24) ? 0u : (0xFFFFFFFFu << (shift + 8));
-      for (long i = tid; i < nbox; i += DJ_MINE_THREADS) {
-        unsigned u = __float_as_uint(negloss[i]);
-        if ((u & himask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
-      }
-      __syncthreads();
-      if (tid == 0) {
-        long need = s_need;
-        int d = 255;
-        for (; d > 0; --d) {
-          if ((long)hist[d] >= need) break;
-          need -= hist[d];
-        }
-        s_need = need;
-        s_prefix = prefix | ((unsigned)d << shift);
-      }
-      __syncthreads();
+    int b;
+    if (level >= 1) {
+      mine_scan_level(hist, DJ_HB, st.need, &b, &st.need);
+      st.prefix = (unsigned)b << 21;
+    }
+    if (level >= 2) {
+      mine_scan_level(hist + DJ_HB, DJ_HB, st.need, &b, &st.need);
+      st.prefix |= (unsigned)b << 10;
+    }
+    if (level >= 3) {
+      mine_scan_level(hist + 2 * DJ_HB, 1024, st.need, &b, &st.need);
+      st.prefix |= (unsigned)b;
     }
   }
-  const unsigned T = s_prefix;  // bits of the k-th largest value
-  long need_eq = s_need;        // how many elements equal to T are kept (lowest indices first)
-  float ksum = 0.f;
-  long taken = 0;
-  for (long base = 0; base < nbox; base += DJ_MINE_THREADS) {
-    long i = base + tid;
-    unsigned u = 0u;
-    float cl = 0.f;
-    bool in = i < nbox;
-    if (in) {
-      u = __float_as_uint(negloss[i]);
-      cl = cls[i];
-    }
-    int eq = (k > 0 && in && u == T) ? 1 : 0;
-    int tot;
-    int rank = block_excl_scan(eq, wsum, &tot);
-    bool kp = k > 0 && in && (u > T || (eq && taken + rank < need_eq));
-    taken += tot;
-    if (in) {
-      keep[i] = kp ? 1.f : 0.f;
-      if (kp) ksum += cl;
-    }
+  return st;
+}
+
+// level 0/1/2 histogram of the elements whose higher bits match the prefix selected so far
+__global__ __launch_bounds__(256) void dj_ssd_mine_hist_kernel(const float* negloss, long nbox, const float* partial,
+                                                                int npartial, unsigned* hist, int level, int ratio,
+                                                                int nmin) {
+  __shared__ unsigned lh[DJ_HB];
+  for (int j = threadIdx.x; j < DJ_HB; j += 256) lh[j] = 0u;
+  MineState st = mine_state(partial, npartial, hist, level, ratio, nmin);
+  if (st.k == 0) return;
+  const unsigned himask = level == 0 ? 0u : (level == 1 ? 0xFFE00000u : 0xFFFFFC00u);
+  const int shift = level == 0 ? 21 : (level == 1 ? 10 : 0);
+  const unsigned dmask = level == 2 ? 1023u : 2047u;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nbox; i += (long)gridDim.x * 256) {
+    unsigned u = __float_as_uint(negloss[i]);
+    if ((u & himask) == st.prefix) atomicAdd(&lh[(u >> shift) & dmask], 1u);
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) ksum += __shfl_xor(ksum, o);
-  if ((tid & 63) == 0) s_keepsum[tid >> 6] = ksum;
   __syncthreads();
-  if (tid == 0) {
-    double ks = 0.0;
-    for (int w = 0; w < DJ_MINE_THREADS / 64; ++w) ks += (double)s_keepsum[w];
-    double npos = dred[0];
-    double denom = npos > 1.0 ? npos : 1.0;
-    double clsp = dred[1] + ks, locp = dred[2];
+  unsigned* gh = hist + level * DJ_HB;
+  for (int j = threadIdx.x; j < DJ_HB; j += 256)
+    if (lh[j]) atomicAdd(&gh[j], lh[j]);
+}
+
+// keep[i] = loss > T, or loss == T while tickets last; per-block sum of the kept classification losses
+__global__ __launch_bounds__(256) void dj_ssd_mine_mark_kernel(const float* cls, const float* negloss, long nbox,
+                                                                const float* partial, int npartial, unsigned* hist,
+                                                                int ratio, int nmin, float* keep, float* keepsum) {
+  __shared__ float red[256];
+  MineState st = mine_state(partial, npartial, hist, 3, ratio, nmin);
+  unsigned* ticket = hist + 3 * DJ_HB;
+  float ks = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nbox; i += (long)gridDim.x * 256) {
+    unsigned u = __float_as_uint(negloss[i]);
+    bool kp = false;
+    if (st.k > 0) {
+      if (u > st.prefix)
+        kp = true;
+      else if (u == st.prefix)
+        kp = (long)atomicAdd(ticket, 1u) < st.need;
+    }
+    keep[i] = kp ? 1.f : 0.f;
+    if (kp) ks += cls[i];
+  }
+  red[threadIdx.x] = ks;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) keepsum[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void dj_ssd_loss_finalize_kernel(const float* partial, int npartial, const unsigned* hist,
+                                                                    const float* keepsum, int nkeep, int ratio, int nmin,
+                                                                    float alpha, float* out) {
+  __shared__ double red[256];
+  MineState st = mine_state(partial, npartial, hist, 0, ratio, nmin);
+  double ks = 0.0;
+  for (int b = threadIdx.x; b < nkeep; b += 256) ks += (double)keepsum[b];
+  red[threadIdx.x] = ks;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double denom = st.npos > 1.0 ? st.npos : 1.0;
+    double clsp = st.spc + red[0], locp = st.spl;
     out[0] = (float)((clsp + (double)alpha * locp) / denom);
-    out[1] = (float)npos;
-    out[2] = (float)k;
+    out[1] = (float)st.npos;
+    out[2] = (float)st.k;
     out[3] = (float)(clsp / denom);
     out[4] = (float)(locp / denom);
   }
@@ -276,13 +339,18 @@ __global__ __launch_bounds__(256) void dj_ssd_loss_bwd_kernel(const float* y_tru
 }
 
 #define DJ_LOSS_BLOCKS 512
+#define DJ_MINE_BLOCKS 256
 
-extern "C" long dj_ssd_loss_workspace_floats(long nbox) { return 5 * nbox + 3 * DJ_LOSS_BLOCKS + 8; }
+// workspace layout (floats): cls[nbox] loc[nbox] pos[nbox] negloss[nbox] keep[nbox] partial[4*DJ_LOSS_BLOCKS]
+//                            keepsum[DJ_MINE_BLOCKS] hist[3*DJ_HB + 8 (ticket)] (as 32-bit words)
+extern "C" long dj_ssd_loss_workspace_floats(long nbox) {
+  return 5 * nbox + 4 * DJ_LOSS_BLOCKS + DJ_MINE_BLOCKS + 3 * DJ_HB + 8 + 8;
+}
 
-// workspace layout: cls[nbox] loc[nbox] pos[nbox] negloss[nbox] keep[nbox] partial[3*DJ_LOSS_BLOCKS]
 extern "C" int dj_ssd_loss_fwd(const float* y_true, const float* y_pred, long nbox, int n_cls, int neg_pos_ratio,
                                int n_neg_min, float alpha, float* workspace, float* out5, void* stream) {
   DJ_CHECK_ARG(y_true && y_pred && workspace && out5 && nbox > 0 && n_cls > 1, "ssd_loss_fwd: bad arguments");
+  DJ_CHECK_ARG(nbox < (1L << 31), "ssd_loss_fwd: too many boxes");
   hipStream_t s = (hipStream_t)stream;
   float* cls = workspace;
   float* loc = cls + nbox;
@@ -290,14 +358,31 @@ extern "C" int dj_ssd_loss_fwd(const float* y_true, const float* y_pred, long nb
   float* negloss = pos + nbox;
   float* keep = negloss + nbox;
   float* partial = keep + nbox;
+  float* keepsum = partial + 4 * DJ_LOSS_BLOCKS;
+  unsigned* hist = reinterpret_cast<unsigned*>(keepsum + DJ_MINE_BLOCKS);
   int blocks = ew_blocks(nbox);
   if (blocks > DJ_LOSS_BLOCKS) blocks = DJ_LOSS_BLOCKS;
+  int mblocks = ew_blocks(nbox);
+  if (mblocks > DJ_MINE_BLOCKS) mblocks = DJ_MINE_BLOCKS;
+  hipError_t e = hipMemsetAsync(hist, 0, (3 * DJ_HB + 8) * sizeof(unsigned), s);
+  if (e != hipSuccess) {
+    dj_set_error("ssd_loss_fwd: memset: %s", hipGetErrorString(e));
+    return DJ_ERR_HIP;
+  }
   hipLaunchKernelGGL(dj_ssd_loss_boxes_kernel, dim3(blocks), dim3(256), 0, s, y_true, y_pred, nbox, n_cls, cls, loc,
                      pos, negloss, partial);
   DJ_CHECK_LAUNCH("dj_ssd_loss_boxes");
-  hipLaunchKernelGGL(dj_ssd_loss_mine_kernel, dim3(1), dim3(DJ_MINE_THREADS), 0, s, cls, negloss, nbox, partial,
-                     blocks, neg_pos_ratio, n_neg_min, alpha, keep, out5);
-  DJ_CHECK_LAUNCH("dj_ssd_loss_mine");
+  for (int level = 0; level < 3; ++level) {
+    hipLaunchKernelGGL(dj_ssd_mine_hist_kernel, dim3(mblocks), dim3(256), 0, s, negloss, nbox, partial, blocks, hist,
+                       level, neg_pos_ratio, n_neg_min);
+    DJ_CHECK_LAUNCH("dj_ssd_mine_hist");
+  }
+  hipLaunchKernelGGL(dj_ssd_mine_mark_kernel, dim3(mblocks), dim3(256), 0, s, cls, negloss, nbox, partial, blocks, hist,
+                     neg_pos_ratio, n_neg_min, keep, keepsum);
+  DJ_CHECK_LAUNCH("dj_ssd_mine_mark");
+  hipLaunchKernelGGL(dj_ssd_loss_finalize_kernel, dim3(1), dim3(256), 0, s, partial, blocks, hist, keepsum, mblocks,
+                     neg_pos_ratio, n_neg_min, alpha, out5);
+  DJ_CHECK_LAUNCH("dj_ssd_loss_finalize");
   return DJ_OK;
 }
 
