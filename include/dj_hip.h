@@ -75,9 +75,11 @@ int dj_conv2d_tune_configs(void);
 int dj_conv2d_tune_set(int dir, const dj_conv2d_desc* d, int cfg, int splits);
 int dj_conv2d_default_config(int dir, const dj_conv2d_desc* d, int* cfg, int* splits);
 
-/* dw = sum over pixels pro(x)^T dy  (TF Conv2DBackpropFilter).  dw is HWIO, overwritten. */
+/* dw = sum over pixels pro(x)^T dy  (TF Conv2DBackpropFilter).  dw is HWIO, overwritten.  The pixel reduction is
+ * split over workgroups that accumulate with fp32 atomics; `dw_zeroed` = 1 promises dw already holds zeros (the engine
+ * clears its whole flat gradient buffer once per step instead of one memset per layer). */
 int dj_conv2d_nhwc_wgrad(const dj_conv2d_desc* d, const float* x, const float* dy, float* dw,
-                         const float* pro_scale, const float* pro_shift, int pro_relu, void* stream);
+                         const float* pro_scale, const float* pro_shift, int pro_relu, int dw_zeroed, void* stream);
 
 /* ---- blocked column reductions (two-stage, deterministic) ------------------------- */
 /* Rows of the `partial` buffers written by the *_partial / *_reduce entry points for a

@@ -48,7 +48,7 @@ SIGNATURES = {
     "dj_conv2d_fwd_stats_rows": (c_int, [POINTER(ConvDesc)]),
     "dj_conv2d_nhwc_fwd": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, FP, c_int, c_int, FP, c_void_p]),
     "dj_conv2d_nhwc_dgrad": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, c_int, c_void_p]),
-    "dj_conv2d_nhwc_wgrad": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, c_int, c_void_p]),
+    "dj_conv2d_nhwc_wgrad": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, c_int, c_int, c_void_p]),
     "dj_set_fast_path": (None, [c_int]),
     "dj_conv2d_tune_configs": (c_int, []),
     "dj_conv2d_tune_set": (c_int, [c_int, POINTER(ConvDesc), c_int, c_int]),

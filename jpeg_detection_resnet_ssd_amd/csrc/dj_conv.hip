@@ -374,7 +374,8 @@ extern "C" int dj_conv2d_nhwc_dgrad(const dj_conv2d_desc* d, const float* dy, co
 }
 
 extern "C" int dj_conv2d_nhwc_wgrad(const dj_conv2d_desc* d, const float* x, const float* dy, float* dw,
-                                    const float* pro_scale, const float* pro_shift, int pro_relu, void* stream) {
+                                    const float* pro_scale, const float* pro_shift, int pro_relu, int dw_zeroed,
+                                    void* stream) {
   if (int rc = check_desc(d)) return rc;
   DJ_CHECK_ARG(x && dy && dw, "conv wgrad: null tensor");
   DJ_CHECK_ARG((pro_scale == nullptr) == (pro_shift == nullptr), "conv wgrad: pro_scale/pro_shift must come together");
@@ -427,10 +428,12 @@ extern "C" int dj_conv2d_nhwc_wgrad(const dj_conv2d_desc* d, const float* x, con
   splits = dj_cdiv(p.K, p.kchunk);
   if (splits > 1) {
     p.atomic = 1;
-    hipError_t e = hipMemsetAsync(dw, 0, (size_t)p.M * p.N * 4, s);
-    if (e != hipSuccess) {
-      dj_set_error("conv wgrad: memset: %s", hipGetErrorString(e));
-      return DJ_ERR_HIP;
+    if (!dw_zeroed) {
+      hipError_t e = hipMemsetAsync(dw, 0, (size_t)p.M * p.N * 4, s);
+      if (e != hipSuccess) {
+        dj_set_error("conv wgrad: memset: %s", hipGetErrorString(e));
+        return DJ_ERR_HIP;
+      }
     }
   }
   return launch_cfg<2, 0>(cfg, p, splits, s);

@@ -26,11 +26,13 @@ struct VecIO<1> {
 // ---------------------------------------------------------------------------------
 // Blocked column reduction: out[blk][q][c] = sum over the block's rows of f_q(row, c), q in {0,1}
 // ---------------------------------------------------------------------------------
+// Every functor maps (row, first column of a group of VEC) -> two per-column contributions.
 struct ColStatsF {  // (x, x^2)
   const float* x;
   int ld;
-  __device__ __forceinline__ void operator()(long r, int c, float& v0, float& v1) const {
-    float v = x[r * ld + c];
+  template <int VEC>
+  __device__ __forceinline__ void eval(long r, int c, f32x4& v0, f32x4& v1) const {
+    f32x4 v = VecIO<VEC>::ld(x + r * ld + c);
     v0 = v;
     v1 = v * v;
   }
@@ -50,16 +52,22 @@ struct BnBwdF {
   const float* scale;
   const float* shift;
   int mask_mode;
-  __device__ __forceinline__ void operator()(long r, int c, float& v0, float& v1) const {
-    float g = dy[r * ld_dy + c];
-    float zz = z[r * ld_z + c];
-    if (mask_mode == 1) {
-      if (!(y[r * ld_y + c] > 0.f)) g = 0.f;
-    } else if (mask_mode == 2) {
-      if (!(zz * scale[c] + shift[c] > 0.f)) g = 0.f;
-    }
+  template <int VEC>
+  __device__ __forceinline__ void eval(long r, int c, f32x4& v0, f32x4& v1) const {
+    using IO = VecIO<VEC>;
+    f32x4 g = IO::ld(dy + r * ld_dy + c);
+    f32x4 zz = IO::ld(z + r * ld_z + c);
+    f32x4 m = {1.f, 1.f, 1.f, 1.f};
+    if (mask_mode == 1)
+      m = IO::ld(y + r * ld_y + c);
+    else if (mask_mode == 2)
+      m = zz * IO::ld(scale + c) + IO::ld(shift + c);
+    g.x = (m.x > 0.f) ? g.x : 0.f;
+    g.y = (m.y > 0.f) ? g.y : 0.f;
+    g.z = (m.z > 0.f) ? g.z : 0.f;
+    g.w = (m.w > 0.f) ? g.w : 0.f;
     v0 = g;
-    v1 = g * (zz - mean[c]) * invstd[c];
+    v1 = g * (zz - IO::ld(mean + c)) * IO::ld(invstd + c);
   }
 };
 
@@ -69,9 +77,10 @@ struct L2DgF {
   const float* x;
   const float* rnorm;
   int ld_dy, ld_x;
-  __device__ __forceinline__ void operator()(long r, int c, float& v0, float& v1) const {
-    v0 = dy[r * ld_dy + c] * x[r * ld_x + c] * rnorm[r];
-    v1 = 0.f;
+  template <int VEC>
+  __device__ __forceinline__ void eval(long r, int c, f32x4& v0, f32x4& v1) const {
+    v0 = VecIO<VEC>::ld(dy + r * ld_dy + c) * VecIO<VEC>::ld(x + r * ld_x + c) * rnorm[r];
+    v1 = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 };
 
@@ -79,27 +88,28 @@ struct L2DgF {
 struct ColSumF {
   const float* dy;
   int ld;
-  __device__ __forceinline__ void operator()(long r, int c, float& v0, float& v1) const {
-    v0 = dy[r * ld + c];
-    v1 = 0.f;
+  template <int VEC>
+  __device__ __forceinline__ void eval(long r, int c, f32x4& v0, f32x4& v1) const {
+    v0 = VecIO<VEC>::ld(dy + r * ld + c);
+    v1 = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 };
 
-// block = 256 threads as (TX columns) x (256/TX rows); grid = (row blocks, column blocks)
-template <typename F>
+// block = 256 threads as (TX column groups of VEC) x (256/TX rows); grid = (row blocks, column blocks)
+template <typename F, int VEC>
 __global__ __launch_bounds__(256) void dj_colreduce_kernel(F f, long rows, int C, int tx_log2, float* partial) {
-  __shared__ float red[2][256];
+  __shared__ f32x4 red[2][256];
   const int TX = 1 << tx_log2;
   const int TY = 256 >> tx_log2;
   const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x >> tx_log2;
-  const int c = blockIdx.y * TX + tx;
+  const int c = (blockIdx.y * TX + tx) * VEC;
   const long r0 = (long)blockIdx.x * DJ_RB;
   const long r1 = (r0 + DJ_RB < rows) ? r0 + DJ_RB : rows;
-  float s0 = 0.f, s1 = 0.f;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
   if (c < C) {
     for (long r = r0 + ty; r < r1; r += TY) {
-      float a, b;
-      f(r, c, a, b);
+      f32x4 a, b;
+      f.template eval<VEC>(r, c, a, b);
       s0 += a;
       s1 += b;
     }
@@ -112,22 +122,29 @@ __global__ __launch_bounds__(256) void dj_colreduce_kernel(F f, long rows, int C
       s0 += red[0][j * TX + tx];
       s1 += red[1][j * TX + tx];
     }
-    partial[((size_t)blockIdx.x * 2 + 0) * C + c] = s0;
-    partial[((size_t)blockIdx.x * 2 + 1) * C + c] = s1;
+    float* p0 = partial + ((size_t)blockIdx.x * 2 + 0) * C + c;
+    float* p1 = partial + ((size_t)blockIdx.x * 2 + 1) * C + c;
+    VecIO<VEC>::st(p0, s0);
+    VecIO<VEC>::st(p1, s1);
   }
 }
 
 template <typename F>
-static int launch_colreduce(F f, long rows, int C, float* partial, hipStream_t s, const char* name) {
+static int launch_colreduce(F f, long rows, int C, bool vec4, float* partial, hipStream_t s, const char* name) {
+  const int groups = vec4 ? C / 4 : C;
   int tx_log2 = 6;
-  while (tx_log2 > 2 && (1 << (tx_log2 - 1)) >= C) --tx_log2;
+  while (tx_log2 > 2 && (1 << (tx_log2 - 1)) >= groups) --tx_log2;
   int TX = 1 << tx_log2;
-  dim3 grid((unsigned)dj_cdiv(rows, DJ_RB), (unsigned)dj_cdiv(C, TX));
-  hipLaunchKernelGGL(dj_colreduce_kernel<F>, grid, dim3(256), 0, s, f, rows, C, tx_log2, partial);
+  dim3 grid((unsigned)dj_cdiv(rows, DJ_RB), (unsigned)dj_cdiv(groups, TX));
+  if (vec4)
+    hipLaunchKernelGGL((dj_colreduce_kernel<F, 4>), grid, dim3(256), 0, s, f, rows, C, tx_log2, partial);
+  else
+    hipLaunchKernelGGL((dj_colreduce_kernel<F, 1>), grid, dim3(256), 0, s, f, rows, C, tx_log2, partial);
   DJ_CHECK_LAUNCH(name);
   return DJ_OK;
 }
 
+static inline bool al16p(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // Column sums of the two partial slots for 32 channels per block: 1024 threads = 32 channels x 32 row
 // lanes, coalesced 128-byte reads, double accumulation.  Valid in threads with ty == 0 (c < C).
@@ -163,13 +180,15 @@ extern "C" int dj_reduce_rows(long rows) { return dj_cdiv(rows, DJ_RB); }
 extern "C" int dj_colstats_partial(const float* x, long rows, int C, int ld, float* partial, void* stream) {
   DJ_CHECK_ARG(x && partial && rows > 0 && C > 0 && ld >= C, "colstats: bad arguments");
   ColStatsF f{x, ld};
-  return launch_colreduce(f, rows, C, partial, (hipStream_t)stream, "dj_colstats_partial");
+  bool v4 = C % 4 == 0 && ld % 4 == 0 && al16p(x) && al16p(partial);
+  return launch_colreduce(f, rows, C, v4, partial, (hipStream_t)stream, "dj_colstats_partial");
 }
 
 extern "C" int dj_colsum_partial(const float* dy, long rows, int C, int ld, float* partial, void* stream) {
   DJ_CHECK_ARG(dy && partial && rows > 0 && C > 0 && ld >= C, "colsum: bad arguments");
   ColSumF f{dy, ld};
-  return launch_colreduce(f, rows, C, partial, (hipStream_t)stream, "dj_colsum_partial");
+  bool v4 = C % 4 == 0 && ld % 4 == 0 && al16p(dy) && al16p(partial);
+  return launch_colreduce(f, rows, C, v4, partial, (hipStream_t)stream, "dj_colsum_partial");
 }
 
 // out[c] (+)= sum_r partial[r][which][c]
@@ -324,7 +343,9 @@ extern "C" int dj_bn_bwd_reduce(const float* dy, int ld_dy, const float* z, int 
   DJ_CHECK_ARG(mask_mode != 1 || y, "bn_bwd_reduce: mask_mode 1 needs y");
   DJ_CHECK_ARG(mask_mode != 2 || (scale && shift), "bn_bwd_reduce: mask_mode 2 needs scale/shift");
   BnBwdF f{dy, ld_dy, z, ld_z, y, ld_y, mean, invstd, scale, shift, mask_mode};
-  return launch_colreduce(f, rows, C, partial, (hipStream_t)stream, "dj_bn_bwd_reduce");
+  bool v4 = C % 4 == 0 && ld_dy % 4 == 0 && ld_z % 4 == 0 && (mask_mode != 1 || ld_y % 4 == 0) && al16p(dy) && al16p(z) &&
+            al16p(y) && al16p(mean) && al16p(invstd) && al16p(scale) && al16p(shift) && al16p(partial);
+  return launch_colreduce(f, rows, C, v4, partial, (hipStream_t)stream, "dj_bn_bwd_reduce");
 }
 
 // dgamma, dbeta and the coefficients of dz = k0*dy_masked + k1*z + k2
@@ -559,7 +580,8 @@ extern "C" int dj_l2norm_bwd(const float* dy, int ld_dy, const float* x, int ldx
   }
   if (dgamma_partial) {
     L2DgF f{dy, x, rnorm, ld_dy, ldx};
-    return launch_colreduce(f, rows, C, dgamma_partial, s, "dj_l2norm_bwd(dgamma)");
+    bool v4 = C % 4 == 0 && ld_dy % 4 == 0 && ldx % 4 == 0 && al16p(dy) && al16p(x) && al16p(dgamma_partial);
+    return launch_colreduce(f, rows, C, v4, dgamma_partial, s, "dj_l2norm_bwd(dgamma)");
   }
   return DJ_OK;
 }

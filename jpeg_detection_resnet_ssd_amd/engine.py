@@ -93,6 +93,7 @@ class Plan(object):
         self.hooks_after_backward = []
         self.grad_ready = {}   # weight key -> index in self.bwd after which its gradient is final
         self.conv_calls = []   # (direction, ConvDesc, launch closure) of every implicit-GEMM call, for autotune()
+        self.grads_cleared = False   # True: the first backward launch zeroes the model's whole flat gradient buffer
 
     # ---- allocation -------------------------------------------------------------
     def empty(self, *shape):
@@ -171,6 +172,12 @@ class Plan(object):
         """Register a function that appends this op's backward launches; builders run in reverse
         registration order once the forward lowering is complete."""
         self._bwd_builders.append(builder)
+
+    def clear_gradients_first(self, flat_grads):
+        """One memset of the flat gradient buffer at the start of backward replaces the per-layer split-K memsets."""
+        assert not self.bwd
+        self.bwd.append(lambda: flat_grads.zero_())
+        self.grads_cleared = True
 
     def build_backward(self):
         for b in reversed(self._bwd_builders):

@@ -299,7 +299,8 @@ class Conv2D(Layer):
                     _bias_grad(plan, dy, self.bias)
             if self.kernel.trainable:
                 dw = self.kernel.grad
-                plan.emit_conv(2, desc, lambda: Kn.conv2d_wgrad(desc, xbuf, dy, dw, pro[0], pro[1], pro[2]), backward=True)
+                plan.emit_conv(2, desc, lambda: Kn.conv2d_wgrad(desc, xbuf, dy, dw, pro[0], pro[1], pro[2],
+                                                                dw_zeroed=plan.grads_cleared), backward=True)
                 plan.note_grad(self.kernel)
             if x.needs_grad:
                 dx, beta = plan.grad_of(x)
@@ -362,7 +363,8 @@ class Conv2DTranspose(Layer):
                 _bias_grad(plan, dy, self.bias)
             if self.kernel.trainable:
                 dw = self.kernel.grad
-                plan.emit_conv(2, desc, lambda: Kn.conv2d_wgrad(desc, dy, xbuf, dw), backward=True)
+                plan.emit_conv(2, desc, lambda: Kn.conv2d_wgrad(desc, dy, xbuf, dw, dw_zeroed=plan.grads_cleared),
+                               backward=True)
                 plan.note_grad(self.kernel)
             if x.needs_grad:
                 dx, beta = plan.grad_of(x)

@@ -239,6 +239,8 @@ class Model(object):
             return self._plans[key]
         self._ensure_params()
         plan = Plan(self._device, batch_size, training)
+        if training:
+            plan.clear_gradients_first(self._store["grads"])
         for lyr in self.layers:
             lyr_ins = [plan.values[id(t)] for t in lyr.inbound]
             if isinstance(lyr, L.InputLayer):

@@ -95,9 +95,9 @@ def conv2d_dgrad(desc, dy, w, dx, bias=None, beta=False):
     return dx
 
 
-def conv2d_wgrad(desc, x, dy, dw, pro_scale=None, pro_shift=None, pro_relu=False):
+def conv2d_wgrad(desc, x, dy, dw, pro_scale=None, pro_shift=None, pro_relu=False, dw_zeroed=False):
     d = _desc_for(desc, x, dy)
     assert dw.is_contiguous() and tuple(dw.shape) == (d.kernel_h, d.kernel_w, d.in_c, d.out_c)
     check(_lib.load().dj_conv2d_nhwc_wgrad(d, ptr(x), ptr(dy), ptr(dw), ptr(pro_scale), ptr(pro_shift),
-                                           int(pro_relu), _stream()), "dj_conv2d_nhwc_wgrad")
+                                           int(pro_relu), int(dw_zeroed), _stream()), "dj_conv2d_nhwc_wgrad")
     return dw
