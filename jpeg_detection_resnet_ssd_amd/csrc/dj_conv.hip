@@ -23,9 +23,9 @@ extern "C" int dj_abi_version(void) { return 1; }
 struct TileCfg {
   int bm, bn;
 };
-static const TileCfg kCfgs[] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {128, 128}, {128, 64}};
+static const TileCfg kCfgs[] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {128, 128}, {128, 64}, {64, 64}};
 // *_S1: same tile with a single LDS stage (fast kernel only; the generic kernel ignores the distinction)
-enum { CFG_128x128 = 0, CFG_128x64, CFG_64x64, CFG_128x32, CFG_128x128_S1, CFG_128x64_S1, N_CFG };
+enum { CFG_128x128 = 0, CFG_128x64, CFG_64x64, CFG_128x32, CFG_128x128_S1, CFG_128x64_S1, CFG_64x64_S1, N_CFG };
 
 template <typename KernT>
 static int launch_kernel(KernT kern, int smem_bytes, int bm, int bn, const DjIgemmParams& p, int splits, hipStream_t s,
@@ -90,6 +90,9 @@ static int launch_cfg(int cfg, const DjIgemmParams& p, int splits, hipStream_t s
     case CFG_128x64_S1:
       return fast ? launch_one<128, 64, 2, 2, AM, BMD, 1>(p, splits, s, fast)
                   : launch_one<128, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);
+    case CFG_64x64_S1:
+      return fast ? launch_one<64, 64, 2, 2, AM, BMD, 1>(p, splits, s, fast)
+                  : launch_one<64, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);
   }
   dj_set_error("bad tile cfg %d", cfg);
   return DJ_ERR_ARG;
