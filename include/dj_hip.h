@@ -170,6 +170,16 @@ int dj_categorical_crossentropy(const float* y_true, const float* probs, long ro
 int dj_sgd_momentum_update(float* param, const float* grad, float* velocity, long n, float lr_t, float momentum,
                            int nesterov, float l2, float grad_scale, float* sumsq, void* stream);
 
+/* ---- DecodeDetections (L/keras_layers/keras_layer_DecodeDetections.py:109-265; numpy twin
+ * L/ssd_encoder_decoder/ssd_output_decoder.py:111-226): y_pred [batch][n_boxes][n_classes+12] (centroid offsets, anchors,
+ * variances in the last 12 columns) -> out [batch][top_k][6] = (class, confidence, xmin, ymin, xmax, ymax) sorted by
+ * confidence, zero padded.  Per class: confidence > thresh, greedy NMS (drop IoU > iou_threshold), at most
+ * nms_max_output_size.  Limits: n_boxes <= 12288, (n_classes-1)*nms_max_output_size <= 8192. ---- */
+long dj_decode_detections_workspace_floats(int batch, int n_boxes, int n_classes, int nms_max_output_size);
+int dj_decode_detections(const float* y_pred, int batch, int n_boxes, int n_classes, float confidence_thresh,
+                         float iou_threshold, int top_k, int nms_max_output_size, int normalize_coords, int img_height,
+                         int img_width, float* workspace, float* out, void* stream);
+
 /* ---- GlobalAveragePooling2D (C/vgg_jpeg_keras/networks/resnet_dct.py:415) ---- */
 int dj_global_avg_pool_fwd(const float* x, float* y, int B, int HW, int C, void* stream);
 int dj_global_avg_pool_bwd(const float* dy, float* dx, int B, int HW, int C, int beta, void* stream);

@@ -79,6 +79,9 @@ SIGNATURES = {
     "dj_ssd_loss_bwd": (c_int, [FP, FP, c_long, c_int, c_float, c_float, FP, FP, FP, c_void_p]),
     "dj_categorical_crossentropy": (c_int, [FP, FP, c_long, c_int, c_float, FP, FP, FP, c_void_p]),
     "dj_sgd_momentum_update": (c_int, [FP, FP, FP, c_long, c_float, c_float, c_int, c_float, c_float, FP, c_void_p]),
+    "dj_decode_detections_workspace_floats": (c_long, [c_int, c_int, c_int, c_int]),
+    "dj_decode_detections": (c_int, [FP, c_int, c_int, c_int, c_float, c_float, c_int, c_int, c_int, c_int, c_int, FP, FP,
+                                     c_void_p]),
     "dj_global_avg_pool_fwd": (c_int, [FP, FP, c_int, c_int, c_int, c_void_p]),
     "dj_global_avg_pool_bwd": (c_int, [FP, FP, c_int, c_int, c_int, c_int, c_void_p]),
 }

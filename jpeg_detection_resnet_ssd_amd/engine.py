@@ -36,7 +36,7 @@ def call(name, *args):
 
 
 def query(name, *args):
-    return check(getattr(_lib.load(), name)(*args), name)
+    return check(getattr(_lib.load(), name)(*[int(a) for a in args]), name)
 
 
 _TUNED = {}   # conv geometry key -> (ms, cfg, splits), process-wide

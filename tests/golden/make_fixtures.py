@@ -80,5 +80,29 @@ def main():
     np.savez(os.path.join(OUT, "encoder_small_minmax.npz"), y_true=small2(gt_small), gt=gt_small[0])
 
 
+def decode_fixture():
+    """Reference numpy decode_detections on synthetic predictions over the real anchor set (2 images, 8732 boxes)."""
+    from ssd_encoder_decoder.ssd_output_decoder import decode_detections
+    enc = SSDInputEncoder(predictor_sizes=SIZES["custom"], **TRAIN)
+    tmpl = enc.generate_encoding_template(batch_size=2)
+    rng = np.random.default_rng(5)
+    n = tmpl.shape[1]
+    logits = rng.normal(0, 1.0, (2, n, 21))
+    logits[..., 0] += 4.0                                   # mostly background
+    hot = rng.choice(n, size=(2, 300), replace=True)
+    for b in range(2):
+        logits[b, hot[b], rng.integers(1, 21, 300)] += rng.uniform(3, 9, 300)
+    p = np.exp(logits - logits.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    y_pred = np.concatenate([p, rng.normal(0, 0.6, (2, n, 4)), tmpl[..., -8:]], axis=-1).astype(np.float32)
+    dec = decode_detections(y_pred.astype(np.float64), confidence_thresh=0.3, iou_threshold=0.45, top_k=200,
+                            normalize_coords=True, img_height=300, img_width=300)
+    dec2 = decode_detections(y_pred.astype(np.float64), confidence_thresh=0.05, iou_threshold=0.45, top_k=50,
+                             normalize_coords=True, img_height=300, img_width=300)
+    np.savez_compressed(os.path.join(OUT, "decode.npz"), y_pred=y_pred, d0=dec[0], d1=dec[1], e0=dec2[0], e1=dec2[1])
+    print("decode fixture: kept", [d.shape for d in dec], [d.shape for d in dec2])
+
+
 if __name__ == "__main__":
     main()
+    decode_fixture()

@@ -1,0 +1,37 @@
+"""Host decoder (numpy) against the fixture produced by the reference's `decode_detections`
+(tests/golden/make_fixtures.py: decode_fixture)."""
+import os
+
+import numpy as np
+
+from jpeg_detection_resnet_ssd_amd.ssd_encoder_decoder.ssd_output_decoder import decode_detections
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "decode.npz")
+
+
+def canon(rows):
+    rows = np.asarray(rows, dtype=np.float64).reshape(-1, 6)
+    return rows[np.lexsort((rows[:, 2], rows[:, 0], -rows[:, 1]))]
+
+
+def test_decode_matches_reference_fixture():
+    g = np.load(GOLD)
+    y = g["y_pred"].astype(np.float64)
+    for thresh, top_k, keys in ((0.3, 200, ("d0", "d1")), (0.05, 50, ("e0", "e1"))):
+        dec = decode_detections(y, confidence_thresh=thresh, iou_threshold=0.45, top_k=top_k, normalize_coords=True,
+                                img_height=300, img_width=300)
+        for got, key in zip(dec, keys):
+            np.testing.assert_allclose(canon(got), canon(g[key]), rtol=0, atol=1e-9)
+
+
+def test_decode_empty_and_errors():
+    g = np.load(GOLD)
+    y = g["y_pred"][:1].astype(np.float64)
+    dec = decode_detections(y, confidence_thresh=0.9999999, top_k=10, img_height=300, img_width=300)
+    assert len(dec) == 1 and dec[0].size == 0
+    try:
+        decode_detections(y, normalize_coords=True)
+    except ValueError:
+        pass
+    else:
+        raise AssertionError("missing image size must raise")
