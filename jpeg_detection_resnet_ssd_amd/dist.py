@@ -119,7 +119,7 @@ class DataParallel(object):
         buckets = plan_buckets(ready, so, self.bucket_bytes)
         ex = self.exchange
         for idx, ranges in sorted(buckets, key=lambda b: -b[0]):
-            plan.bwd.insert(idx, (lambda r=ranges: ex.launch(r)))
+            plan.bwd.insert(idx, (lambda r=ranges: (plan.join_side(), ex.launch(r))))
         self._attached.add(id(plan))
         self.n_buckets = len(buckets)
 

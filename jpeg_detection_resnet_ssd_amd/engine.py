@@ -16,10 +16,22 @@ Backward lists are built in a second pass, in exactly the order they will execut
 hands out the gradient buffer of a Value and tells the caller whether it is the first writer
 (store) or a later one (accumulate, `beta=1` epilogues), so fan-out needs no extra add kernels.
 """
+import os
+
 import torch
 
 from . import _lib
 from ._lib import check
+
+_SIDE = {}
+
+
+def _side_stream(device):
+    """One extra HIP stream per device, shared by all plans of the process."""
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
 
 
 def _conv(a):
@@ -94,6 +106,13 @@ class Plan(object):
         self.grad_ready = {}   # weight key -> index in self.bwd after which its gradient is final
         self.conv_calls = []   # (direction, ConvDesc, launch closure) of every implicit-GEMM call, for autotune()
         self.grads_cleared = False   # True: the first backward launch zeroes the model's whole flat gradient buffer
+        # weight-gradient GEMMs only feed the optimizer, so they run on a second HIP stream and fill the CUs the
+        # data-gradient chain leaves idle at its tile-quantisation tails (DJ_SIDE_WGRAD=0 keeps one stream)
+        self.side_stream = None
+        self._side_dirty = False
+        if training and device.type == "cuda" and os.environ.get("DJ_SIDE_WGRAD", "1") != "0":
+            self.side_stream = _side_stream(device)
+            self._join_event = torch.cuda.Event()
 
     # ---- allocation -------------------------------------------------------------
     def empty(self, *shape):
@@ -113,10 +132,32 @@ class Plan(object):
     def emit_bwd(self, fn):
         self.bwd.append(fn)
 
-    def emit_conv(self, direction, desc, fn, backward=False):
-        """Record one implicit-GEMM launch (direction 0 fwd / 1 dgrad / 2 wgrad, +4 = forward with BN statistics)."""
-        (self.bwd if backward else self.fwd).append(fn)
+    def emit_conv(self, direction, desc, fn, backward=False, side=False):
+        """Record one implicit-GEMM launch (direction 0 fwd / 1 dgrad / 2 wgrad, +4 = forward with BN statistics).
+        side=True: the launch has no consumer before the optimizer / gradient exchange and every buffer it reads is
+        final when it is issued, so it may run on the plan's side stream."""
         self.conv_calls.append((direction, desc, fn))
+        if side and backward and self.side_stream is not None:
+            fn = self._on_side(fn)
+        (self.bwd if backward else self.fwd).append(fn)
+
+    def _on_side(self, fn):
+        side, ready = self.side_stream, torch.cuda.Event()
+
+        def run():
+            ready.record()                      # everything issued so far on the main stream (dy, the memset)
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                fn()
+            self._side_dirty = True
+        return run
+
+    def join_side(self):
+        """Make the main stream wait for the side-stream launches issued so far."""
+        if self._side_dirty:
+            self._join_event.record(self.side_stream)
+            torch.cuda.current_stream().wait_event(self._join_event)
+            self._side_dirty = False
 
     def autotune(self, reps=2, verbose=False):
         """Time every distinct conv geometry of this plan under each tile configuration / split-K factor on the
@@ -208,6 +249,7 @@ class Plan(object):
     def run_backward(self):
         for f in self.bwd:
             f()
+        self.join_side()
         for h in self.hooks_after_backward:
             h()
 

@@ -300,7 +300,8 @@ class Conv2D(Layer):
             if self.kernel.trainable:
                 dw = self.kernel.grad
                 plan.emit_conv(2, desc, lambda: Kn.conv2d_wgrad(desc, xbuf, dy, dw, pro[0], pro[1], pro[2],
-                                                                dw_zeroed=plan.grads_cleared), backward=True)
+                                                                dw_zeroed=plan.grads_cleared), backward=True,
+                               side=True)
                 plan.note_grad(self.kernel)
             if x.needs_grad:
                 dx, beta = plan.grad_of(x)

@@ -31,5 +31,12 @@ for name, key, e0, e1, fl in recs:
 tot = sum(a[1] for a in agg.values())
 print("total conv ms %.2f, TF %.1f" % (tot, sum(a[2] for a in agg.values()) / tot / 1e9))
 print("%-13s %-44s %4s %8s %7s %6s" % ("op", "B,H,W,Cin,OH,Cout,k,s,d", "n", "ms", "TF", "%"))
-for (name, key), a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+for (name, key), a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("%-13s %-44s %4d %8.3f %7.1f %6.1f" % (name, str(key), a[0], a[1], a[2] / a[1] / 1e9, 100 * a[1] / tot))
+for d in ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad"):
+    t = sum(a[1] for (n, k), a in agg.items() if n == d); f = sum(a[2] for (n, k), a in agg.items() if n == d)
+    print("%s: %.2f ms, %.1f TF, %d launches" % (d, t, f / t / 1e9, sum(a[0] for (n, k), a in agg.items() if n == d)))
+ideal = sum(a[2] for a in agg.values()) / 130e9
+print("time above 130 TF/s pace: %.2f ms of %.2f" % (tot - ideal, tot))
+lost = sorted(((a[1] - a[2] / 130e9, n, k, a[0]) for (n, k), a in agg.items()), reverse=True)[:25]
+for l, n, k, c in lost: print("lost %.3f ms  %s %s x%d" % (l, n, k, c))
