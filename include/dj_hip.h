@@ -141,11 +141,14 @@ int dj_l2norm_bwd(const float* dy, int ld_dy, const float* x, int ldx, const flo
 /* ---- keras.layers.MaxPooling2D: `pool5_ssd` (3,3)/1/'same' (L/models/...resnet.py:481,1110) and the ResNet50RGB
  * stem ZeroPadding2D(1) + (3,3)/2 (C/vgg_jpeg_keras/networks/resnet_dct.py:165-314).  pt/pl = leading pads;
  * pad_zero = 1 when the padding comes from a ZeroPadding2D (zeros take part in the max), 0 for TF 'same'/'valid'.
- * The gradient goes to the first maximum of each window in row-major order. ---- */
+ * The gradient goes to the first maximum of each window in row-major order.  `argmax` (optional, B*OH*OW*C bytes):
+ * forward stores each window's winning tap there and backward reads it instead of rescanning the windows
+ * (then `x` may be NULL in backward). ---- */
 int dj_maxpool2d_fwd(const float* x, float* y, int B, int H, int W, int C, int OH, int OW, int kh, int kw, int sh,
-                     int sw, int pt, int pl, int pad_zero, void* stream);
+                     int sw, int pt, int pl, int pad_zero, unsigned char* argmax, void* stream);
 int dj_maxpool2d_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int OH, int OW, int kh,
-                     int kw, int sh, int sw, int pt, int pl, int pad_zero, int beta, void* stream);
+                     int kw, int sh, int sw, int pt, int pl, int pad_zero, int beta, const unsigned char* argmax,
+                     void* stream);
 
 /* ---- Activation('softmax') on the last axis (L/models/...resnet.py:873; Dense(..., softmax)) ---- */
 int dj_softmax_fwd(const float* x, float* y, long rows, int C, void* stream);

@@ -70,8 +70,8 @@ SIGNATURES = {
     "dj_upsample2x": (c_int, [FP, c_int, FP, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dj_l2norm_fwd": (c_int, [FP, c_int, FP, FP, c_int, FP, c_long, c_int, c_void_p]),
     "dj_l2norm_bwd": (c_int, [FP, c_int, FP, c_int, FP, FP, FP, c_int, FP, c_long, c_int, c_int, c_void_p]),
-    "dj_maxpool2d_fwd": (c_int, [FP, FP] + [c_int] * 13 + [c_void_p]),
-    "dj_maxpool2d_bwd": (c_int, [FP, FP, FP] + [c_int] * 14 + [c_void_p]),
+    "dj_maxpool2d_fwd": (c_int, [FP, FP] + [c_int] * 13 + [c_void_p, c_void_p]),
+    "dj_maxpool2d_bwd": (c_int, [FP, FP, FP] + [c_int] * 14 + [c_void_p, c_void_p]),
     "dj_softmax_fwd": (c_int, [FP, FP, c_long, c_int, c_void_p]),
     "dj_softmax_bwd": (c_int, [FP, FP, c_long, FP, c_long, c_int, c_int, c_void_p]),
     "dj_ssd_loss_workspace_floats": (c_long, [c_long]),

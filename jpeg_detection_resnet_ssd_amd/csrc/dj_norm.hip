@@ -157,10 +157,39 @@ __device__ __forceinline__ void dj_partial_sums(const float* partial, int nrows,
   const int c = blockIdx.x * 32 + tx;
   double a = 0.0, b = 0.0;
   if (c < C) {
-    for (int r = ty; r < nrows; r += 32) {
+    // four rows in flight per thread: the loop is latency-bound (a few dozen dependent loads otherwise)
+    double a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0, a3 = 0.0, b3 = 0.0;
+    int r = ty;
+    for (; r + 96 < nrows; r += 128) {
+      const float* p = partial + (size_t)r * 2 * C + c;
+      float x0 = 0.f, x1 = 0.f, x2 = 0.f, x3 = 0.f, y0 = 0.f, y1 = 0.f, y2 = 0.f, y3 = 0.f;
+      if (which_mask & 1) {
+        x0 = p[0];
+        x1 = p[(size_t)64 * C];
+        x2 = p[(size_t)128 * C];
+        x3 = p[(size_t)192 * C];
+      }
+      if (which_mask & 2) {
+        y0 = p[C];
+        y1 = p[(size_t)65 * C];
+        y2 = p[(size_t)129 * C];
+        y3 = p[(size_t)193 * C];
+      }
+      a += (double)x0;
+      a1 += (double)x1;
+      a2 += (double)x2;
+      a3 += (double)x3;
+      b += (double)y0;
+      b1 += (double)y1;
+      b2 += (double)y2;
+      b3 += (double)y3;
+    }
+    for (; r < nrows; r += 32) {
       if (which_mask & 1) a += (double)partial[((size_t)r * 2 + 0) * C + c];
       if (which_mask & 2) b += (double)partial[((size_t)r * 2 + 1) * C + c];
     }
+    a += a1 + a2 + a3;
+    b += b1 + b2 + b3;
   }
   red0[ty][tx] = a;
   red1[ty][tx] = b;
@@ -617,7 +646,8 @@ __device__ __forceinline__ float pool_window(const float* x, const PoolGeom& g, 
   return m;
 }
 
-__global__ __launch_bounds__(256) void dj_maxpool2d_fwd_kernel(const float* x, float* y, PoolGeom g) {
+__global__ __launch_bounds__(256) void dj_maxpool2d_fwd_kernel(const float* x, float* y, unsigned char* argmax,
+                                                                PoolGeom g) {
   long total = (long)g.B * g.OH * g.OW * g.C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     int c = (int)(i % g.C);
@@ -628,12 +658,15 @@ __global__ __launch_bounds__(256) void dj_maxpool2d_fwd_kernel(const float* x, f
     int b = (int)(q / g.OH);
     int ah, aw;
     y[i] = pool_window(x, g, b, oh, ow, c, &ah, &aw);
+    // window-relative tap of the winner (255: a zero pad tap), so that backward need not rescan the windows
+    if (argmax) argmax[i] = ah < 0 ? 255 : (unsigned char)((ah - (oh * g.sh - g.pt)) * g.kw + (aw - (ow * g.sw - g.pl)));
   }
 }
 
 // gather form: each input element sums the gradients of the windows whose (first) maximum it is
-__global__ __launch_bounds__(256) void dj_maxpool2d_bwd_kernel(const float* x, const float* dy, float* dx, PoolGeom g,
-                                                                int beta) {
+template <bool SAVED>
+__global__ __launch_bounds__(256) void dj_maxpool2d_bwd_kernel(const float* x, const unsigned char* argmax, const float* dy,
+                                                                float* dx, PoolGeom g, int beta) {
   long total = (long)g.B * g.H * g.W * g.C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     int c = (int)(i % g.C);
@@ -654,9 +687,16 @@ __global__ __launch_bounds__(256) void dj_maxpool2d_bwd_kernel(const float* x, c
     if (ow_hi >= g.OW) ow_hi = g.OW - 1;
     for (int oh = oh_lo; oh <= oh_hi; ++oh)
       for (int ow = ow_lo; ow <= ow_hi; ++ow) {
-        int ah, aw;
-        pool_window(x, g, b, oh, ow, c, &ah, &aw);
-        if (ah == h && aw == w) acc += dy[((long)(b * g.OH + oh) * g.OW + ow) * g.C + c];
+        long o = ((long)(b * g.OH + oh) * g.OW + ow) * g.C + c;
+        bool mine;
+        if (SAVED) {
+          mine = (int)argmax[o] == (h - (oh * g.sh - g.pt)) * g.kw + (w - (ow * g.sw - g.pl));
+        } else {
+          int ah, aw;
+          pool_window(x, g, b, oh, ow, c, &ah, &aw);
+          mine = ah == h && aw == w;
+        }
+        if (mine) acc += dy[o];
       }
     dx[i] = beta ? dx[i] + acc : acc;
   }
@@ -673,23 +713,29 @@ static int pool_geom(PoolGeom* g, int B, int H, int W, int C, int OH, int OW, in
 }
 
 extern "C" int dj_maxpool2d_fwd(const float* x, float* y, int B, int H, int W, int C, int OH, int OW, int kh, int kw,
-                                int sh, int sw, int pt, int pl, int pad_zero, void* stream) {
+                                int sh, int sw, int pt, int pl, int pad_zero, unsigned char* argmax, void* stream) {
   DJ_CHECK_ARG(x && y, "maxpool fwd: null tensor");
+  DJ_CHECK_ARG(!argmax || kh * kw < 255, "maxpool fwd: window too large for the saved arg-max encoding");
   PoolGeom g;
   if (int rc = pool_geom(&g, B, H, W, C, OH, OW, kh, kw, sh, sw, pt, pl, pad_zero)) return rc;
   hipLaunchKernelGGL(dj_maxpool2d_fwd_kernel, dim3(ew_blocks((long)B * OH * OW * C)), dim3(256), 0, (hipStream_t)stream,
-                     x, y, g);
+                     x, y, argmax, g);
   DJ_CHECK_LAUNCH("dj_maxpool2d_fwd");
   return DJ_OK;
 }
 
 extern "C" int dj_maxpool2d_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int OH, int OW,
-                                int kh, int kw, int sh, int sw, int pt, int pl, int pad_zero, int beta, void* stream) {
-  DJ_CHECK_ARG(x && dy && dx, "maxpool bwd: null tensor");
+                                int kh, int kw, int sh, int sw, int pt, int pl, int pad_zero, int beta,
+                                const unsigned char* argmax, void* stream) {
+  DJ_CHECK_ARG((x || argmax) && dy && dx, "maxpool bwd: null tensor");
   PoolGeom g;
   if (int rc = pool_geom(&g, B, H, W, C, OH, OW, kh, kw, sh, sw, pt, pl, pad_zero)) return rc;
-  hipLaunchKernelGGL(dj_maxpool2d_bwd_kernel, dim3(ew_blocks((long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, x,
-                     dy, dx, g, beta);
+  if (argmax)
+    hipLaunchKernelGGL(dj_maxpool2d_bwd_kernel<true>, dim3(ew_blocks((long)B * H * W * C)), dim3(256), 0,
+                       (hipStream_t)stream, x, argmax, dy, dx, g, beta);
+  else
+    hipLaunchKernelGGL(dj_maxpool2d_bwd_kernel<false>, dim3(ew_blocks((long)B * H * W * C)), dim3(256), 0,
+                       (hipStream_t)stream, x, argmax, dy, dx, g, beta);
   DJ_CHECK_LAUNCH("dj_maxpool2d_bwd");
   return DJ_OK;
 }

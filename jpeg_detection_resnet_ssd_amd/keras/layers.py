@@ -798,7 +798,10 @@ class MaxPooling2D(Layer):
         kh, kw = self.pool_size
         sh, sw = self.strides
         y = plan.empty(b, oh, ow, c)
-        plan.emit(lambda: call("dj_maxpool2d_fwd", xbuf, y, b, h, w, c, oh, ow, kh, kw, sh, sw, pt, pl, pad_zero))
+        amax = None
+        if plan.training and x.needs_grad:
+            amax = torch.empty(b * oh * ow * c, dtype=torch.uint8, device=plan.device)
+        plan.emit(lambda: call("dj_maxpool2d_fwd", xbuf, y, b, h, w, c, oh, ow, kh, kw, sh, sw, pt, pl, pad_zero, amax))
         out = Value(y, needs_grad=x.needs_grad, name=self.name)
 
         def build_backward():
@@ -808,7 +811,7 @@ class MaxPooling2D(Layer):
             dx, beta = plan.grad_of(x)
             assert dx.is_contiguous() and dy.is_contiguous()
             plan.emit_bwd(lambda: call("dj_maxpool2d_bwd", xbuf, dy, dx, b, h, w, c, oh, ow, kh, kw, sh, sw, pt, pl,
-                                       pad_zero, beta))
+                                       pad_zero, beta, amax))
 
         plan.on_backward(build_backward)
         return out

@@ -132,23 +132,28 @@ def test_l2norm(shape, cuda, E):
     assert close(dg, gr.grad)
 
 
+@pytest.mark.parametrize("saved", [False, True])
 @pytest.mark.parametrize("hw", [5, 10])
-def test_maxpool(hw, cuda, E):
+def test_maxpool(hw, saved, cuda, E):
     g = torch.Generator().manual_seed(9)
-    x = torch.randn(3, hw, hw, 256, generator=g)
+    x = torch.relu(torch.randn(3, hw, hw, 256, generator=g))     # exact ties (zeros): first maximum must win
     dy = torch.randn(3, hw, hw, 256, generator=g)
     xr = x.double().requires_grad_(True)
     yr = ko.max_pool_3x3_s1_same(xr)
     yr.backward(dy.double())
     y, dx = torch.empty(x.shape, device=cuda), torch.empty(x.shape, device=cuda)
-    E.call("dj_maxpool2d_fwd", x.to(cuda), y, 3, hw, hw, 256, hw, hw, 3, 3, 1, 1, 1, 1, 0)
-    E.call("dj_maxpool2d_bwd", x.to(cuda), dy.to(cuda), dx, 3, hw, hw, 256, hw, hw, 3, 3, 1, 1, 1, 1, 0, 0)
+    am = torch.empty(x.numel(), dtype=torch.uint8, device=cuda) if saved else None
+    E.call("dj_maxpool2d_fwd", x.to(cuda), y, 3, hw, hw, 256, hw, hw, 3, 3, 1, 1, 1, 1, 0, am)
+    E.call("dj_maxpool2d_bwd", None if saved else x.to(cuda), dy.to(cuda), dx, 3, hw, hw, 256, hw, hw, 3, 3, 1, 1, 1, 1,
+           0, 0, am)
     torch.cuda.synchronize()
     assert torch.equal(y.cpu().double(), yr.detach())
+    # ties: torch's CPU max_pool2d also routes the gradient to the first maximum in window order
     assert close(dx, xr.grad, rel=1e-5)
 
 
-def test_maxpool_stem_zero_padded_stride2(cuda, E):
+@pytest.mark.parametrize("saved", [False, True])
+def test_maxpool_stem_zero_padded_stride2(saved, cuda, E):
     """ZeroPadding2D(1) + MaxPooling2D((3,3), strides 2): the ResNet50RGB stem (zeros take part in the max)."""
     g = torch.Generator().manual_seed(19)
     b, hw, c = 2, 12, 64
@@ -159,8 +164,9 @@ def test_maxpool_stem_zero_padded_stride2(cuda, E):
     dy = torch.randn(yr.shape, generator=g)
     yr.backward(dy.double())
     y, dx = torch.empty(yr.shape, device=cuda), torch.ones(x.shape, device=cuda)
-    E.call("dj_maxpool2d_fwd", x.to(cuda), y, b, hw, hw, c, oh, oh, 3, 3, 2, 2, 1, 1, 1)
-    E.call("dj_maxpool2d_bwd", x.to(cuda), dy.to(cuda), dx, b, hw, hw, c, oh, oh, 3, 3, 2, 2, 1, 1, 1, 1)
+    am = torch.empty(y.numel(), dtype=torch.uint8, device=cuda) if saved else None
+    E.call("dj_maxpool2d_fwd", x.to(cuda), y, b, hw, hw, c, oh, oh, 3, 3, 2, 2, 1, 1, 1, am)
+    E.call("dj_maxpool2d_bwd", x.to(cuda), dy.to(cuda), dx, b, hw, hw, c, oh, oh, 3, 3, 2, 2, 1, 1, 1, 1, am)
     torch.cuda.synchronize()
     assert torch.equal(y.cpu().double(), yr.detach())
     assert close(dx - 1.0, xr.grad, rel=1e-5)
