@@ -51,9 +51,11 @@ def measure_conv_kernels(model, plan):
     for n in ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad"):
         wrap(n)
     try:
+        plan.side_enabled = False      # one stream: a launch's events bracket that launch alone
         model.run_train_step(plan)
         torch.cuda.synchronize()
     finally:
+        plan.side_enabled = True
         for n, f in originals.items():
             setattr(Kn, n, f)
     total_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in records)
@@ -97,7 +99,7 @@ def cpu_baseline(archi, batch, budget_s=25.0):
         times.append(time.perf_counter() - t0)
         print("cpu_baseline: step %d took %.2f s on %d threads" % (len(times), times[-1], cores), file=sys.stderr,
               flush=True)
-        if time.perf_counter() - t_start > budget_s or len(times) >= 6:
+        if time.perf_counter() - t_start > budget_s or len(times) >= 40:
             break
     use = times[1:] if len(times) > 1 else times   # first step pays one-time allocator / thread-pool start-up
     med = float(np.median(use))
@@ -181,6 +183,11 @@ def main():
     roof = {"bound": "mfma", "achieved": per_gpu_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": per_gpu_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
             "note": "whole-step algorithmic conv FLOPs (SURVEY 8(d) table) / step time, per GPU"}
+    traffic_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_igemm_traffic.json")
+    if os.path.exists(traffic_file) and args.archi == "deconv" and args.batch == 32:
+        # offline rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_e_hbm_traffic.md), bytes per launch
+        with open(traffic_file) as f:
+            roof["traffic"] = json.load(f)["bytes_per_launch"]
     if world == 1:
         k = measure_conv_kernels(model, plan)
         ktf = k["flop"] / (k["total_ms"] * 1e-3) / 1e12

@@ -52,6 +52,36 @@ def query(name, *args):
 
 
 _TUNED = {}   # conv geometry key -> (ms, cfg, splits), process-wide
+_TUNE_DB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gfx950_conv.json")
+_DB = None    # "dir,geometry..." -> [cfg, splits, ms]: tile choices measured once on an MI355X and shipped in-tree
+
+
+def _tune_db():
+    """The in-tree table of measured tile choices (like a find-db: geometry -> kernel variant).  Geometries it does
+    not hold are timed at plan time; DJ_TUNE_DB=path selects another file, DJ_TUNE_DB=0 ignores it."""
+    global _DB
+    if _DB is None:
+        _DB = {}
+        path = os.environ.get("DJ_TUNE_DB", _TUNE_DB)
+        if path != "0" and os.path.exists(path):
+            import json
+            with open(path) as f:
+                _DB = json.load(f).get("entries", {})
+    return _DB
+
+
+def save_tune_db(path=None):
+    """Write every choice made in this process (measured or loaded) to `path`."""
+    import json
+    entries = dict(_tune_db())
+    for key, (ms, cfg, sp) in _TUNED.items():
+        entries[",".join(str(int(v)) for v in key)] = [int(cfg), int(sp), round(float(ms), 5)]
+    path = path or _TUNE_DB
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as f:
+        json.dump({"arch": "gfx950", "abi": int(_lib.load().dj_abi_version()), "n_configs":
+                   int(_lib.load().dj_conv2d_tune_configs()), "entries": entries}, f, indent=0, sort_keys=True)
+    return len(entries)
 
 
 class GradRef(object):
@@ -109,6 +139,7 @@ class Plan(object):
         # weight-gradient GEMMs only feed the optimizer, so they run on a second HIP stream and fill the CUs the
         # data-gradient chain leaves idle at its tile-quantisation tails (DJ_SIDE_WGRAD=0 keeps one stream)
         self.side_stream = None
+        self.side_enabled = True     # cleared while kernels are timed one by one (bench.py)
         self._side_dirty = False
         if training and device.type == "cuda" and os.environ.get("DJ_SIDE_WGRAD", "1") != "0":
             self.side_stream = _side_stream(device)
@@ -145,6 +176,8 @@ class Plan(object):
         side, ready = self.side_stream, torch.cuda.Event()
 
         def run():
+            if not self.side_enabled:
+                return fn()
             ready.record()                      # everything issued so far on the main stream (dy, the memset)
             side.wait_event(ready)
             with torch.cuda.stream(side):
@@ -171,6 +204,11 @@ class Plan(object):
         for direction, desc, fn in self.conv_calls:
             key = (direction,) + tuple(getattr(desc, n) for n in names)
             if key in _TUNED:
+                continue
+            known = _tune_db().get(",".join(str(int(v)) for v in key))
+            if known is not None and known[0] < ncfg:
+                check(lib.dj_conv2d_tune_set(direction, desc, int(known[0]), int(known[1])), "tune_set")
+                _TUNED[key] = (float(known[2]), int(known[0]), int(known[1]))
                 continue
             c0, s0 = ctypes.c_int(0), ctypes.c_int(1)
             check(lib.dj_conv2d_default_config(direction, desc, ctypes.byref(c0), ctypes.byref(s0)), "default_config")

@@ -263,7 +263,11 @@ class Model(object):
         if training:
             plan.build_backward()
         if os.environ.get("DJ_AUTOTUNE", "1") != "0":
-            plan.autotune(verbose=os.environ.get("DJ_AUTOTUNE_VERBOSE", "0") == "1")
+            plan.autotune(reps=int(os.environ.get("DJ_AUTOTUNE_REPS", "2")),
+                          verbose=os.environ.get("DJ_AUTOTUNE_VERBOSE", "0") == "1")
+            if os.environ.get("DJ_TUNE_SAVE"):
+                from ..engine import save_tune_db
+                save_tune_db(os.environ["DJ_TUNE_SAVE"])
         if training:
             if self.dist is not None and with_loss:
                 self.dist.attach(plan)
