@@ -183,6 +183,18 @@ int dj_decode_detections(const float* y_pred, int batch, int n_boxes, int n_clas
                          float iou_threshold, int top_k, int nms_max_output_size, int normalize_coords, int img_height,
                          int img_width, float* workspace, float* out, void* stream);
 
+/* ---- SSDInputEncoder.__call__ for coords='centroids' (L/ssd_encoder_decoder/ssd_input_encoder.py:277-418,
+ * matching_utils.py:22-116, L/bounding_box_utils/bounding_box_utils.py:283-383): labels [batch][max_gt][5] =
+ * (class id, xmin, ymin, xmax, ymax) in pixels (float64, as the reference computes), n_gt [batch] valid rows,
+ * anchors [n_boxes][8] = template anchor (cx, cy, w, h) + 4 variances (float64) -> y_true [batch][n_boxes]
+ * [n_classes + 12] fp32.  n_classes includes the background class.  border_pixels: 0 'half', 1 'include', -1
+ * 'exclude'; multi = 1 for matching_type 'multi'.  Limits: max_gt <= 128, n_boxes <= 12288.  Degenerate boxes
+ * (xmax <= xmin ...) must be rejected by the caller, as the reference raises DegenerateBoxError on the host. ---- */
+int dj_ssd_encode_targets(const double* labels, const int* n_gt, int batch, int max_gt, const double* anchors,
+                          int n_boxes, int n_classes, int img_height, int img_width, int normalize_coords,
+                          int border_pixels, int multi, double pos_iou_threshold, double neg_iou_limit,
+                          int background_id, float* y_true, void* stream);
+
 /* ---- GlobalAveragePooling2D (C/vgg_jpeg_keras/networks/resnet_dct.py:415) ---- */
 int dj_global_avg_pool_fwd(const float* x, float* y, int B, int HW, int C, void* stream);
 int dj_global_avg_pool_bwd(const float* dy, float* dx, int B, int HW, int C, int beta, void* stream);

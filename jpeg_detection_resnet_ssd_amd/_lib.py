@@ -4,7 +4,7 @@ There is no CPU fallback: if the library is missing the import of any compute en
 raises, and every call checks the return code and raises `DjError` with dj_last_error()."""
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_long, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdj_hip.so")
@@ -82,6 +82,8 @@ SIGNATURES = {
     "dj_decode_detections_workspace_floats": (c_long, [c_int, c_int, c_int, c_int]),
     "dj_decode_detections": (c_int, [FP, c_int, c_int, c_int, c_float, c_float, c_int, c_int, c_int, c_int, c_int, FP, FP,
                                      c_void_p]),
+    "dj_ssd_encode_targets": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                      c_int, c_double, c_double, c_int, FP, c_void_p]),
     "dj_global_avg_pool_fwd": (c_int, [FP, FP, c_int, c_int, c_int, c_void_p]),
     "dj_global_avg_pool_bwd": (c_int, [FP, FP, c_int, c_int, c_int, c_int, c_void_p]),
 }

@@ -325,7 +325,12 @@ class Model(object):
                 raise ValueError("Error when checking input: expected shape %s but got array with shape %s"
                                  % (tuple(buf.shape), tuple(t.shape)))
             buf.copy_(t.to(torch.float32), non_blocking=True)
-        if y is not None:
+        if y is not None and hasattr(y, "encode_into"):      # PendingTargets: SSDInputEncoder runs on the device
+            if tuple(y.shape) != tuple(plan.y_true.shape):
+                raise ValueError("Error when checking target: expected shape %s but got array with shape %s"
+                                 % (tuple(plan.y_true.shape), tuple(y.shape)))
+            y.encode_into(plan.y_true)
+        elif y is not None:
             t = y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(y))
             if tuple(t.shape) != tuple(plan.y_true.shape):
                 raise ValueError("Error when checking target: expected shape %s but got array with shape %s"

@@ -161,3 +161,94 @@ class SSDInputEncoder:
             matched[:, :, -12:-8] = 0
             return y, matched
         return y
+
+    # ---- the same encoding on the GPU ------------------------------------------------------------------------
+    def encode_on_device(self, ground_truth_labels, out=None, device=None):
+        """`__call__` computed by the HIP kernel `dj_ssd_encode_targets` (float64 arithmetic in the reference's order
+        of operations, so the matches are the host's): -> float32 CUDA tensor (batch, #boxes, #classes + 12), written
+        into `out` when given (e.g. a plan's resident `y_true` buffer).  Only the labels (a few KB) cross PCIe."""
+        import torch
+        from ..engine import call
+        if self.coords != "centroids":
+            raise NotImplementedError("encode_on_device supports coords='centroids' (the trainer's setting) only")
+        if self.matching_type not in ("multi", "bipartite"):
+            raise ValueError("unknown matching_type %r" % (self.matching_type,))
+        batch_size = len(ground_truth_labels)
+        max_gt = max([1] + [len(g) for g in ground_truth_labels])
+        labels = np.zeros((batch_size, max_gt, 5), dtype=np.float64)
+        counts = np.zeros(batch_size, dtype=np.int32)
+        for i, gt in enumerate(ground_truth_labels):
+            gt = np.asarray(gt)
+            if gt.size == 0:
+                continue
+            lab = gt.astype(float)
+            if np.any(lab[:, 3] - lab[:, 1] <= 0) or np.any(lab[:, 4] - lab[:, 2] <= 0):
+                raise DegenerateBoxError(
+                    "SSDInputEncoder detected degenerate ground truth bounding boxes for batch item {} with bounding "
+                    "boxes {}, i.e. bounding boxes where xmax <= xmin and/or ymax <= ymin. Degenerate ground truth "
+                    "bounding boxes will lead to NaN errors during the training.".format(i, lab))
+            cls = lab[:, 0].astype(int)
+            if np.any(cls < 0) or np.any(cls >= self.n_classes):
+                raise IndexError("class id out of range for {} classes (incl. background)".format(self.n_classes))
+            labels[i, :len(lab)] = lab[:, :5]
+            counts[i] = len(lab)
+        if device is None:
+            device = out.device if out is not None else torch.device("cuda", torch.cuda.current_device())
+        key = str(device)
+        cache = self.__dict__.setdefault("_device_anchors", {})
+        if key not in cache:
+            cache[key] = torch.from_numpy(np.ascontiguousarray(self.generate_encoding_template(1)[0, :, -8:])).to(device)
+        anchors = cache[key]
+        n_boxes = anchors.shape[0]
+        if out is None:
+            out = torch.empty(batch_size, n_boxes, self.n_classes + 12, dtype=torch.float32, device=device)
+        assert out.is_contiguous() and tuple(out.shape) == (batch_size, n_boxes, self.n_classes + 12)
+        lab_d = torch.from_numpy(labels).to(device, non_blocking=True)
+        cnt_d = torch.from_numpy(counts).to(device, non_blocking=True)
+        border = {"half": 0, "include": 1, "exclude": -1}[self.border_pixels]
+        call("dj_ssd_encode_targets", lab_d, cnt_d, batch_size, max_gt, anchors, n_boxes, self.n_classes,
+             int(self.img_height), int(self.img_width), int(bool(self.normalize_coords)), border,
+             int(self.matching_type == "multi"), float(self.pos_iou_threshold), float(self.neg_iou_limit),
+             int(self.background_id), out)
+        return out
+
+
+
+class PendingTargets(object):
+    """Ground-truth boxes of one batch, to be encoded straight into the model's resident `y_true` buffer."""
+
+    def __init__(self, encoder, ground_truth_labels):
+        self.encoder = encoder
+        self.ground_truth_labels = [np.asarray(g, dtype=float).reshape(-1, 5) if np.size(g) else np.zeros((0, 5))
+                                    for g in ground_truth_labels]
+
+    def __len__(self):
+        return len(self.ground_truth_labels)
+
+    @property
+    def shape(self):
+        return (len(self.ground_truth_labels), self.encoder.generate_encoding_template(1).shape[1],
+                self.encoder.n_classes + 12)
+
+    def encode_into(self, out):
+        return self.encoder.encode_on_device(self.ground_truth_labels, out=out)
+
+    def numpy(self):
+        return self.encoder(self.ground_truth_labels)
+
+
+class DeviceLabelEncoder(object):
+    """Drop-in for the `label_encoder=` argument of the reference's data generators
+    (localisation_part/training_dct_pascal_j2d_resnet.py:244-265): the generator thread only packs the boxes; the
+    matching runs on the GPU when `Model.fit_generator / train_on_batch` uploads the batch."""
+
+    def __init__(self, encoder):
+        self.encoder = encoder
+
+    def __call__(self, ground_truth_labels, diagnostics=False):
+        if diagnostics:
+            return self.encoder(ground_truth_labels, diagnostics=True)
+        return PendingTargets(self.encoder, ground_truth_labels)
+
+    def __getattr__(self, name):
+        return getattr(self.encoder, name)
