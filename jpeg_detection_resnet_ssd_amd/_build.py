@@ -9,6 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libdj_hip.so")
+JPEG_LIB_PATH = os.path.join(CSRC, "libdj_jpeg.so")
 ARCH = "gfx950"
 
 
@@ -55,7 +56,21 @@ def build_library(force=False, verbose=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    build_jpeg_library(force)
     return LIB_PATH
+
+
+def build_jpeg_library(force=False):
+    """Host-only JPEG coefficient reader (csrc/dj_jpeg.cpp -> csrc/libdj_jpeg.so), plain g++."""
+    src = os.path.join(CSRC, "dj_jpeg.cpp")
+    hdr = os.path.join(CSRC, "..", "..", "include", "dj_jpeg.h")
+    if force or _newer([src, hdr], JPEG_LIB_PATH):
+        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", src, "-o",
+               JPEG_LIB_PATH]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("g++ failed for dj_jpeg.cpp:\n%s\n%s" % (r.stdout, r.stderr))
+    return JPEG_LIB_PATH
 
 
 if __name__ == "__main__":
