@@ -101,3 +101,36 @@ def test_inference_mode_model():
         np.testing.assert_array_equal(got[:, 0], want[:, 0])
         np.testing.assert_allclose(got[:, 1], want[:, 1], rtol=1e-5)
         np.testing.assert_allclose(got[:, 2:], want[:, 2:], atol=5e-2)
+
+
+def test_evaluator_runs_an_inference_model_end_to_end():
+    """Evaluator + mode='inference' model (on-device DecodeDetections) over a small synthetic set; with mode='training'
+    + host decode_detections the per-class prediction lists are the same."""
+    from jpeg_detection_resnet_ssd_amd import workloads
+    from jpeg_detection_resnet_ssd_amd.data.generators import SyntheticDataGeneratorDCT
+    from jpeg_detection_resnet_ssd_amd.eval_utils.average_precision_evaluator import Evaluator
+    from jpeg_detection_resnet_ssd_amd.keras import backend as K
+    from jpeg_detection_resnet_ssd_amd.models.keras_ssd300_dct_j2d_resnet import ssd_resnet_EF_layers_custom
+    train, sizes = workloads.build_ssd("ssd_custom", compile_model=False)
+    weights = train.get_weights_dict()
+    for k in weights:
+        if "mbox_loc" in k or "mbox_conf" in k:
+            weights[k] = weights[k] * 1e-5
+    train.set_weights_dict(weights)
+    K.clear_session()
+    infer = ssd_resnet_EF_layers_custom(archi="ssd_custom", **dict(workloads.SSD_ARGS, mode="inference",
+                                                                  confidence_thresh=0.05, top_k=20))
+    infer.set_weights_dict(weights)
+    data = SyntheticDataGeneratorDCT(n_images=6, seed=11)
+    ev_i = Evaluator(infer, 20, data, model_mode="inference")
+    # border_pixels also steers the host decoder's NMS ('include' adds 1 px to the areas, TF's NMS in the layer does not)
+    m_i = ev_i(300, 300, batch_size=4, verbose=False, border_pixels="half")
+    ev_t = Evaluator(train, 20, data, model_mode="training")
+    m_t = ev_t(300, 300, batch_size=4, verbose=False, decoding_confidence_thresh=0.05, decoding_top_k=20,
+               border_pixels="half")
+    assert 0.0 <= m_i <= 1.0 and abs(m_i - m_t) < 1e-9
+    for c in range(1, 21):
+        a = sorted((p[0], round(float(p[1]), 5)) for p in ev_i.prediction_results[c])
+        b = sorted((p[0], round(float(p[1]), 5)) for p in ev_t.prediction_results[c])
+        assert a == b
+    assert sum(len(r) for r in ev_i.prediction_results) == 6 * 20
