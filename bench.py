@@ -108,7 +108,7 @@ def cpu_baseline(archi, batch, budget_s=25.0):
                       "at batch %d; median step %.2f s" % (len(use), archi, batch, med)}
 
 
-def main():
+def main(json_out=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -198,11 +198,17 @@ def main():
     out["roofline"] = roof
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.archi, args.cpu_batch, args.cpu_budget)
-    print(json.dumps(out))
+    print(json.dumps(out), file=json_out or sys.stdout, flush=True)
 
 
 if __name__ == "__main__":
-    main()
+    # stdout carries exactly one JSON line: libraries that print banners on fd 1 (RCCL's version block at communicator
+    # creation) are sent to stderr while the benchmark runs
+    sys.stdout.flush()
+    _real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    _json_out = os.fdopen(_real_stdout, "w")
+    main(_json_out)
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
