@@ -7,7 +7,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdj_hip.so")
+LIB_PATH = os.environ.get("DJ_LIB_PATH") or os.path.join(_HERE, "csrc", "libdj_hip.so")   # override: kernel experiments
 
 
 class DjError(RuntimeError):

@@ -23,9 +23,24 @@ extern "C" int dj_abi_version(void) { return 1; }
 struct TileCfg {
   int bm, bn;
 };
-static const TileCfg kCfgs[] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {128, 128}, {128, 64}, {64, 64}};
-// *_S1: same tile with a single LDS stage (fast kernel only; the generic kernel ignores the distinction)
-enum { CFG_128x128 = 0, CFG_128x64, CFG_64x64, CFG_128x32, CFG_128x128_S1, CFG_128x64_S1, CFG_64x64_S1, N_CFG };
+static const TileCfg kCfgs[] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {128, 128}, {128, 64}, {64, 64}, {64, 64}, {128, 64}, {128, 128}, {128, 64}, {64, 64}};
+// *_S1: same tile with a single LDS stage; *_S1P: single stage with loads two K-steps ahead; *_P: two stages with
+// the pinned-load / read-ahead schedule (fast kernel only; the generic kernel ignores the distinction)
+enum {
+  CFG_128x128 = 0,
+  CFG_128x64,
+  CFG_64x64,
+  CFG_128x32,
+  CFG_128x128_S1,
+  CFG_128x64_S1,
+  CFG_64x64_S1,
+  CFG_64x64_S1P,
+  CFG_128x64_S1P,
+  CFG_128x128_P,
+  CFG_128x64_P,
+  CFG_64x64_P,
+  N_CFG
+};
 
 template <typename KernT>
 static int launch_kernel(KernT kern, int smem_bytes, int bm, int bn, const DjIgemmParams& p, int splits, hipStream_t s,
@@ -50,7 +65,7 @@ template <int BM, int BN, int WM, int WN, int AM, int BMD, int NSTAGE>
 static int launch_one(const DjIgemmParams& p, int splits, hipStream_t s, int fast) {
   using Cfg = DjIgemmCfg<BM, BN, WM, WN, AM, BMD>;
   static bool done[3] = {false, false, false};
-  const int smem_fast = Cfg::SMEM_BYTES / 2 * NSTAGE;
+  const int smem_fast = Cfg::SMEM_BYTES / 2 * ((NSTAGE == 2 || NSTAGE == 4) ? 2 : 1);
   if (fast == 1)
     return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 0, NSTAGE>, smem_fast, BM, BN, p, splits, s,
                          &done[1]);
@@ -92,6 +107,21 @@ static int launch_cfg(int cfg, const DjIgemmParams& p, int splits, hipStream_t s
                   : launch_one<128, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);
     case CFG_64x64_S1:
       return fast ? launch_one<64, 64, 2, 2, AM, BMD, 1>(p, splits, s, fast)
+                  : launch_one<64, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);
+    case CFG_64x64_S1P:
+      return fast ? launch_one<64, 64, 2, 2, AM, BMD, 3>(p, splits, s, fast)
+                  : launch_one<64, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);
+    case CFG_128x64_S1P:
+      return fast ? launch_one<128, 64, 2, 2, AM, BMD, 3>(p, splits, s, fast)
+                  : launch_one<128, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);
+    case CFG_128x128_P:
+      return fast ? launch_one<128, 128, 2, 2, AM, BMD, 4>(p, splits, s, fast)
+                  : launch_one<128, 128, 2, 2, AM, BMD, 2>(p, splits, s, fast);
+    case CFG_128x64_P:
+      return fast ? launch_one<128, 64, 2, 2, AM, BMD, 4>(p, splits, s, fast)
+                  : launch_one<128, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);
+    case CFG_64x64_P:
+      return fast ? launch_one<64, 64, 2, 2, AM, BMD, 4>(p, splits, s, fast)
                   : launch_one<64, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);
   }
   dj_set_error("bad tile cfg %d", cfg);

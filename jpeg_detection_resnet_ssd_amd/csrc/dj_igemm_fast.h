@@ -141,11 +141,23 @@ __global__ __launch_bounds__(256) void dj_igemm_fast_kernel(const DjIgemmParams 
     t_kw = t_tap - t_kh * p.KW;
   }
 
-  f32x4 ra[NA], rb[NB];
-  unsigned a_valid = 0;  // bit j: row j of the prefetched A tile is in bounds (needed when PRO)
-  f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+  // one K-step's operands in flight: registers between the buffer loads and the LDS writes
+  struct Regs {
+    f32x4 ra[NA], rb[NB];
+    unsigned a_valid;  // bit j: row j of the prefetched A tile is in bounds (needed when PRO)
+    f32x4 psc, psh;
+  };
+  Regs r0, r1;
+  r0.a_valid = r1.a_valid = 0;
+  r0.psc = r1.psc = f32x4{1.f, 1.f, 1.f, 1.f};
+  r0.psh = r1.psh = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto issue_loads = [&](int kcur, bool live) {
+  auto issue_loads = [&](Regs& R, int kcur, bool live) {
+    f32x4(&ra)[NA] = R.ra;
+    f32x4(&rb)[NB] = R.rb;
+    unsigned& a_valid = R.a_valid;
+    f32x4& psc = R.psc;
+    f32x4& psh = R.psh;
     // ---- A ----
     if (AM != 2) {
       const int dh = t_kh * p.dH, dw = t_kw * p.dW;
@@ -214,7 +226,10 @@ __global__ __launch_bounds__(256) void dj_igemm_fast_kernel(const DjIgemmParams 
     }
   };
 
-  auto transform = [&]() {
+  auto transform = [&](Regs& R) {
+    f32x4(&ra)[NA] = R.ra;
+    const unsigned a_valid = R.a_valid;
+    const f32x4 psc = R.psc, psh = R.psh;
     if (PRO) {
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
@@ -230,7 +245,9 @@ __global__ __launch_bounds__(256) void dj_igemm_fast_kernel(const DjIgemmParams 
     }
   };
 
-  auto store_tiles = [&](float* sA, float* sB) {
+  auto store_tiles = [&](const Regs& R, float* sA, float* sB) {
+    const f32x4(&ra)[NA] = R.ra;
+    const f32x4(&rb)[NB] = R.rb;
     if (AM != 2) {
 #pragma unroll
       for (int j = 0; j < NA; ++j) *reinterpret_cast<f32x4*>(sA + (ar0 + 32 * j) * LDA_S + 4 * ac) = ra[j];
@@ -254,46 +271,76 @@ __global__ __launch_bounds__(256) void dj_igemm_fast_kernel(const DjIgemmParams 
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // a wave with a single 32x32 output tile would issue one dependent MFMA chain; a second accumulator for the odd
+  // k pairs gives the matrix pipe two independent chains (summed before the epilogue)
+  constexpr bool DUAL = (TM * TN == 1);
+  f32x16 acc_odd;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc_odd[r] = 0.f;
 
-  // one 8-deep k group: fragment reads + 4*TM*TN MFMAs
-  auto compute_kk = [&](const float* sA, const float* sB, int kk) {
-    f32x4 af[TM], bf[TN];
+  // one 8-deep k group = one fragment set (TM + TN b128 registers) feeding 4*TM*TN MFMAs
+  struct Frag {
+    f32x4 a[TM], b[TN];
+  };
+  auto read_frag = [&](Frag& f, const float* sA, const float* sB, int kk) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       int row = (wm * TM + i) * 32 + l31;
       if (Cfg::A_KC) {
-        af[i] = *reinterpret_cast<const f32x4*>(sA + row * LDA_S + kk * 8 + lh * 4);
+        f.a[i] = *reinterpret_cast<const f32x4*>(sA + row * LDA_S + kk * 8 + lh * 4);
       } else {
         const float* q = sA + (kk * 8 + lh * 4) * LDA_S + row;
-        af[i].x = q[0];
-        af[i].y = q[LDA_S];
-        af[i].z = q[2 * LDA_S];
-        af[i].w = q[3 * LDA_S];
+        f.a[i].x = q[0];
+        f.a[i].y = q[LDA_S];
+        f.a[i].z = q[2 * LDA_S];
+        f.a[i].w = q[3 * LDA_S];
       }
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       int col = (wn * TN + j) * 32 + l31;
       if (Cfg::B_KC) {
-        bf[j] = *reinterpret_cast<const f32x4*>(sB + col * LDB_S + kk * 8 + lh * 4);
+        f.b[j] = *reinterpret_cast<const f32x4*>(sB + col * LDB_S + kk * 8 + lh * 4);
       } else {
         const float* q = sB + (kk * 8 + lh * 4) * LDB_S + col;
-        bf[j].x = q[0];
-        bf[j].y = q[LDB_S];
-        bf[j].z = q[2 * LDB_S];
-        bf[j].w = q[3 * LDB_S];
+        f.b[j].x = q[0];
+        f.b[j].y = q[LDB_S];
+        f.b[j].z = q[2 * LDB_S];
+        f.b[j].w = q[3 * LDB_S];
       }
     }
+  };
+  auto mma = [&](const Frag& f) {
+    if (DUAL) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+      for (int e = 0; e < 4; e += 2) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[0][e], f.b[0][e], acc[0][0], 0, 0, 0);
+        acc_odd = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[0][e + 1], f.b[0][e + 1], acc_odd, 0, 0, 0);
+      }
+    } else {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][e], f.b[j][e], acc[i][j], 0, 0, 0);
+    }
+  };
+  auto compute_kk = [&](const float* sA, const float* sB, int kk) {
+    Frag f;
+    read_frag(f, sA, sB, kk);
+    mma(f);
   };
 
-  // one K-step on compile-time LDS stage `S`: prefetch tile kt+1 while the MFMAs of tile kt run
+  // One K-step on compile-time LDS stage `S` (two-stage ring), two schedules:
+  // NSTAGE == 2: prefetch tile kt+1 while the MFMAs of tile kt run; the compiler places the loads (it sinks them
+  //   towards their use: fewest registers, most resident workgroups).
+  // NSTAGE == 4 ("pipelined"): entry: F0 holds the kk = 0 fragments of stage S.  Loads of tile kt+1 pinned at the top
+  //   (a whole step of MFMAs to land); fragments read one k group ahead of the MFMAs that use them; tile kt+1 goes to
+  //   the other stage, barrier, and the FIRST fragments of that stage are read BEFORE the last k group's MFMAs are
+  //   issued, so the LDS latency across the step boundary hides behind them.  Wins when few workgroups share a CU.
+  Frag F0, F1;
   auto kstep = [&](auto stage_tag, int kt) {
     constexpr int S = decltype(stage_tag)::value;
     float* curA = smem + S * STAGE;
@@ -302,21 +349,38 @@ __global__ __launch_bounds__(256) void dj_igemm_fast_kernel(const DjIgemmParams 
     float* nxtB = nxtA + AFL;
     // the loads of a non-existent next tile are issued with out-of-range offsets (they return zeros
     // without touching memory) so that the K-step stays one straight-line block
-    issue_loads(kbeg + (kt + 1) * DJ_BK, kt + 1 < nk);
-    compute_kk(curA, curB, 0);
-    compute_kk(curA, curB, 1);
-    compute_kk(curA, curB, 2);
-    transform();
-    store_tiles(nxtA, nxtB);
-    compute_kk(curA, curB, 3);
-    __syncthreads();
+    issue_loads(r0, kbeg + (kt + 1) * DJ_BK, kt + 1 < nk);
+    if (NSTAGE == 4) {
+      __builtin_amdgcn_sched_barrier(0);
+      read_frag(F1, curA, curB, 1);
+      mma(F0);
+      read_frag(F0, curA, curB, 2);
+      mma(F1);
+      read_frag(F1, curA, curB, 3);
+      mma(F0);
+      transform(r0);
+      store_tiles(r0, nxtA, nxtB);
+      __syncthreads();
+      read_frag(F0, nxtA, nxtB, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(F1);
+    } else {
+      compute_kk(curA, curB, 0);
+      compute_kk(curA, curB, 1);
+      compute_kk(curA, curB, 2);
+      transform(r0);
+      store_tiles(r0, nxtA, nxtB);
+      compute_kk(curA, curB, 3);
+      __syncthreads();
+    }
   };
 
-  issue_loads(kbeg, nk > 0);
-  transform();
-  store_tiles(smem, smem + AFL);
+  issue_loads(r0, kbeg, nk > 0);
+  transform(r0);
+  store_tiles(r0, smem, smem + AFL);
   __syncthreads();
-  if (NSTAGE == 2) {
+  if (NSTAGE == 2 || NSTAGE == 4) {
+    if (NSTAGE == 4) read_frag(F0, smem, smem + AFL, 0);
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) {
       kstep(std::integral_constant<int, 0>{}, kt);
@@ -324,20 +388,50 @@ __global__ __launch_bounds__(256) void dj_igemm_fast_kernel(const DjIgemmParams 
     }
     if (kt < nk) kstep(std::integral_constant<int, 0>{}, kt);
   } else {
-    // single LDS stage (half the LDS, twice the resident workgroups): the next tile waits in registers
-    // while this one is consumed; two barriers per K-step
-    for (int kt = 0; kt < nk; ++kt) {
-      issue_loads(kbeg + (kt + 1) * DJ_BK, kt + 1 < nk);
-      compute_kk(smem, smem + AFL, 0);
-      compute_kk(smem, smem + AFL, 1);
-      compute_kk(smem, smem + AFL, 2);
-      compute_kk(smem, smem + AFL, 3);
-      transform();
-      __syncthreads();
-      store_tiles(smem, smem + AFL);
-      __syncthreads();
+    // single LDS stage (half the LDS, twice the resident workgroups), two barriers per K-step
+    if (NSTAGE == 1) {
+      // the next tile waits in registers while this one is consumed; few registers, up to 8 workgroups per CU hide
+      // the load latency for each other
+      for (int kt = 0; kt < nk; ++kt) {
+        issue_loads(r0, kbeg + (kt + 1) * DJ_BK, kt + 1 < nk);
+        compute_kk(smem, smem + AFL, 0);
+        compute_kk(smem, smem + AFL, 1);
+        compute_kk(smem, smem + AFL, 2);
+        compute_kk(smem, smem + AFL, 3);
+        transform(r0);
+        __syncthreads();
+        store_tiles(r0, smem, smem + AFL);
+        __syncthreads();
+      }
+    } else {
+      // NSTAGE == 3: as above, but the loads run TWO K-steps ahead (pinned above the MFMAs): a load has 2 x 16 x 64
+      // MFMA cycles of a 32x32 wave tile to land.  For launches with too few workgroups per CU to hide latency by
+      // occupancy; costs ~30 VGPRs.
+      auto s1_step = [&](Regs& cur, Regs& nxt, int kt) {
+        issue_loads(nxt, kbeg + (kt + 2) * DJ_BK, kt + 2 < nk);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_kk(smem, smem + AFL, 0);
+        compute_kk(smem, smem + AFL, 1);
+        compute_kk(smem, smem + AFL, 2);
+        compute_kk(smem, smem + AFL, 3);
+        transform(cur);
+        __syncthreads();
+        store_tiles(cur, smem, smem + AFL);
+        __syncthreads();
+      };
+      issue_loads(r0, kbeg + DJ_BK, 1 < nk);
+      int kt = 0;
+      for (; kt + 1 < nk; kt += 2) {
+        s1_step(r0, r1, kt);
+        s1_step(r1, r0, kt + 1);
+      }
+      if (kt < nk) s1_step(r0, r1, kt);
     }
   }
 
+  if (DUAL) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] += acc_odd[r];
+  }
   dj_igemm_epilogue<BM, BN, WM, WN>(p, acc, smem, tile_m, m0, n0);
 }

@@ -13,6 +13,11 @@ x = torch.randn(b, h, w, ci, device=dev); wt = torch.randn(k, k, ci, co, device=
 y = torch.empty(b, desc.out_h, desc.out_w, co, device=dev); dy = torch.randn_like(y); dx = torch.empty_like(x); dw = torch.empty_like(wt)
 sc = torch.rand(ci, device=dev) + 0.5; sh = torch.randn(ci, device=dev)
 stats = torch.empty(K.conv2d_stats_rows(desc), 2, co, device=dev)
+if os.environ.get("DJ_CFG"):   # "cfg,splits": pin the tile variant (dj_conv2d_tune_set)
+    from jpeg_detection_resnet_ssd_amd import _lib
+    cfg, sp = [int(v) for v in os.environ["DJ_CFG"].split(",")]
+    direction = {"fwd": 4 if pro else 0, "dgrad": 1, "wgrad": 2}[mode]
+    _lib.check(_lib.load().dj_conv2d_tune_set(direction, desc, cfg, sp), "tune_set")
 for _ in range(5):
     if mode == "fwd":
         K.conv2d_fwd(desc, x, wt, bias, y, sc if pro else None, sh if pro else None, pro, False, stats if pro else None)

@@ -41,3 +41,18 @@ for e in win:
     agg[n][0] += 1; agg[n][1] += e[1] - e[0]
 for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
     print("%8.3f ms/step %6.1f calls/step  %s" % (t / 1e6 / nsteps, c / nsteps, n))
+# ---- exclusive / shared time of the two queues inside the window
+qs = sorted(byq)
+if len(qs) == 2:
+    evs = []
+    for qi, q in enumerate(qs):
+        for e in byq[q]:
+            evs.append((e[0], 1, qi)); evs.append((e[1], -1, qi))
+    evs.sort()
+    act = [0, 0]; last = evs[0][0]; tot = {"none": 0, "only0": 0, "only1": 0, "both": 0}
+    for t, d, qi in evs:
+        key = "both" if act[0] and act[1] else ("only0" if act[0] else ("only1" if act[1] else "none"))
+        tot[key] += t - last; last = t
+        act[qi] += d
+    print("per step: main only %.2f ms, side only %.2f ms, both %.2f ms, none %.2f ms" % tuple(tot[k] / 1e6 / nsteps for k in ("only0", "only1", "both", "none")))
+    # last kernel end per queue relative to each step's marker
