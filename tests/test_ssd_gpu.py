@@ -105,7 +105,7 @@ def check_gradients_and_update(grads, ref, ref32, w0, w1, reg=(), l2=0.0):
         assert err <= 1e-3 * float(v.abs().max()) + 0.25 * step + 1e-12, k
 
 
-@pytest.mark.parametrize("archi", ["ssd_custom", "deconv", "up_sampling"])
+@pytest.mark.parametrize("archi", ["ssd_custom", "deconv", "up_sampling", "y_cb4_cbcr_cb5", "cb5_only"])
 def test_training_step_matches_oracle(archi, cuda):
     """Forward, loss and updated weights at 1e-3.  Gradients: ReLU decisions on the tiny 5x5..1x1 maps
     make a few gradients of this deep, batch-2 case ill-conditioned in ANY fp32 implementation: see
