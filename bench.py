@@ -115,6 +115,9 @@ def main(json_out=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--archi", default="deconv", choices=["deconv", "ssd_custom", "up_sampling"])
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (the reference trainer's batch_size)")
+    ap.add_argument("--floatx", default="float32", choices=["float32", "float16", "bfloat16"],
+                    help="conv arithmetic: float32 = exact fp32 MFMA (the headline); float16 / bfloat16 = BASELINE config 5's "
+                         "reduced-precision MFMA with fp32 master tensors and accumulation (reported with its own dtype)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of CPU work for the cpu_baseline sample")
@@ -129,6 +132,8 @@ def main(json_out=None):
         raise SystemExit("bench.py needs an MI355X: the compute path has no CPU fallback")
     torch.cuda.set_device(local)
 
+    from jpeg_detection_resnet_ssd_amd.keras import backend as K
+    K.set_floatx(args.floatx)
     model, sizes = workloads.build_ssd(args.archi)
     model._ensure_params()
     dp = None
@@ -174,7 +179,8 @@ def main(json_out=None):
         "metric": "images/sec (train) ResNet50-DCT-SSD300",
         "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": {"float32": "f32", "float16": "f16/bf16-mfma+f32-acc", "bfloat16": "bf16-mfma+f32-acc"}[args.floatx],
+        "data": "synthetic",
         "config": {"workload": "SSD300 ResNet50-DCT '%s' archi, %d images/GPU, 300x300 JPEG-DCT inputs "
                                "(Y 38x38x64 + chroma 19x19), fwd+loss+bwd+SGD(+RCCL all-reduce)" % (args.archi, args.batch),
                    "archi": args.archi, "global_batch": world * args.batch, "parallelism": "dp%d" % world,

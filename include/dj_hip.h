@@ -68,6 +68,14 @@ int dj_conv2d_nhwc_dgrad(const dj_conv2d_desc* d, const float* dy, const float* 
  * launcher pick the branch-free buffer-load kernel whenever its alignment preconditions hold. */
 void dj_set_fast_path(int enable);
 
+/* Arithmetic of the implicit-GEMM kernels (BASELINE config 5, "fp16 MFMA"): 0 = exact fp32 MFMA (default; what every
+ * parity claim at 1e-3 refers to); 1 = forward GEMMs round both operands to fp16 and gradient GEMMs (dgrad, wgrad,
+ * Conv2DTranspose forward) to bf16 as the fragments leave LDS, v_mfma_f32_32x32x8_{f16,bf16} with fp32 accumulation;
+ * 2 = bf16 in every GEMM.  Tensors in HBM (activations, weights = the fp32 master copy, gradients, optimizer state)
+ * stay fp32 in every mode.  Process-wide; returns the previous mode. */
+int dj_set_compute_mode(int mode);
+int dj_get_compute_mode(void);
+
 /* Launch-configuration overrides per conv geometry, filled by the plan-time autotuner: `dir` 0 fwd, 1 dgrad,
  * 2 wgrad (+4: forward that takes BN statistics); cfg in [0, dj_conv2d_tune_configs()) selects the tile shape
  * (128x128, 128x64, 64x64, 128x32), `splits` the split-K factor; cfg < 0 removes the override. */

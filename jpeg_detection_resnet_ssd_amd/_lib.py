@@ -50,6 +50,8 @@ SIGNATURES = {
     "dj_conv2d_nhwc_dgrad": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, c_int, c_void_p]),
     "dj_conv2d_nhwc_wgrad": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, c_int, c_int, c_void_p]),
     "dj_set_fast_path": (None, [c_int]),
+    "dj_set_compute_mode": (c_int, [c_int]),
+    "dj_get_compute_mode": (c_int, []),
     "dj_conv2d_tune_configs": (c_int, []),
     "dj_conv2d_tune_set": (c_int, [c_int, POINTER(ConvDesc), c_int, c_int]),
     "dj_conv2d_default_config": (c_int, [c_int, POINTER(ConvDesc), POINTER(c_int), POINTER(c_int)]),

@@ -78,6 +78,16 @@ static int launch_one(const DjIgemmParams& p, int splits, hipStream_t s, int fas
 static bool g_allow_fast = true;
 extern "C" void dj_set_fast_path(int enable) { g_allow_fast = enable != 0; }
 
+// 0: fp32 MFMA everywhere (default).  1: forward GEMMs round their operands to fp16, gradient GEMMs (dgrad, wgrad) to
+// bf16 (gradients need the exponent range); 2: bf16 everywhere.  fp32 accumulation and fp32 tensors in all modes.
+static int g_compute_mode = 0;
+extern "C" int dj_set_compute_mode(int mode) {
+  int prev = g_compute_mode;
+  if (mode >= 0 && mode <= 2) g_compute_mode = mode;
+  return prev;
+}
+extern "C" int dj_get_compute_mode(void) { return g_compute_mode; }
+
 // Preconditions of dj_igemm_fast_kernel (see its header comment).
 template <int AM, int BMD>
 static int fast_mode(const DjIgemmParams& p) {
@@ -91,9 +101,35 @@ static int fast_mode(const DjIgemmParams& p) {
   return p.pro_scale ? 2 : 1;
 }
 
+// reduced-precision MFMA variants exist for the two-stage 128x128 / 128x64 / 64x64 tiles of the fast kernel
+template <int BM, int BN, int AM, int BMD, int PREC>
+static int launch_lowp(const DjIgemmParams& p, int splits, hipStream_t s, int fast) {
+  using Cfg = DjIgemmCfg<BM, BN, 2, 2, AM, BMD>;
+  static bool done[2] = {false, false};
+  if (fast == 1)
+    return launch_kernel(dj_igemm_fast_kernel<BM, BN, 2, 2, AM, BMD, 0, 2, PREC>, Cfg::SMEM_BYTES, BM, BN, p, splits, s,
+                         &done[0]);
+  return launch_kernel(dj_igemm_fast_kernel<BM, BN, 2, 2, AM, BMD, 1, 2, PREC>, Cfg::SMEM_BYTES, BM, BN, p, splits, s,
+                       &done[1]);
+}
+
+template <int AM, int BMD, int PREC>
+static int launch_lowp_cfg(int cfg, const DjIgemmParams& p, int splits, hipStream_t s, int fast) {
+  const int bm = kCfgs[cfg].bm, bn = kCfgs[cfg].bn;
+  if (bm == 128 && bn == 128) return launch_lowp<128, 128, AM, BMD, PREC>(p, splits, s, fast);
+  if (bm == 128 && bn == 64) return launch_lowp<128, 64, AM, BMD, PREC>(p, splits, s, fast);
+  return launch_lowp<64, 64, AM, BMD, PREC>(p, splits, s, fast);   // 64x64 and 128x32 requests
+}
+
 template <int AM, int BMD>
 static int launch_cfg(int cfg, const DjIgemmParams& p, int splits, hipStream_t s) {
   const int fast = fast_mode<AM, BMD>(p);
+  if (fast && g_compute_mode != 0 && cfg >= 0 && cfg < N_CFG) {
+    // A-mode 0 with B-mode 0 is the forward GEMM; everything else carries gradients
+    const bool forward = (AM == 0 && BMD == 0);
+    if (g_compute_mode == 1 && forward) return launch_lowp_cfg<AM, BMD, 1>(cfg, p, splits, s, fast);
+    return launch_lowp_cfg<AM, BMD, 2>(cfg, p, splits, s, fast);
+  }
   switch (cfg) {
     case CFG_128x128: return launch_one<128, 128, 2, 2, AM, BMD, 2>(p, splits, s, fast);
     case CFG_128x64: return launch_one<128, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);

@@ -28,8 +28,23 @@ __device__ __forceinline__ f32x4 dj_buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned o
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
 }
 
+typedef _Float16 dj_half4 __attribute__((ext_vector_type(4)));
+typedef short dj_short4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ dj_half4 dj_to_half4(f32x4 v) {
+  return dj_half4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};   // round-to-nearest-even
+}
+__device__ __forceinline__ dj_short4 dj_to_bf16x4(f32x4 v) {
+  __bf16 a = (__bf16)v.x, b = (__bf16)v.y, c = (__bf16)v.z, d = (__bf16)v.w;       // v_cvt_pk_bf16_f32 (RNE) on gfx950
+  return dj_short4{__builtin_bit_cast(short, a), __builtin_bit_cast(short, b), __builtin_bit_cast(short, c),
+                   __builtin_bit_cast(short, d)};
+}
+
 // PRO: 0 = plain A, 1 = A*scale[c]+shift[c] (then max(., floor) with floor = 0 or -inf) on in-bounds elements
-template <int BM, int BN, int WM, int WN, int AM, int BMD, int PRO, int NSTAGE = 2>
+// PREC: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1 = operands rounded to fp16, 2 = to bf16 when the fragments
+//       are read, one v_mfma_f32_32x32x8_{f16,bf16} per 8-deep k group (same lane <-> k mapping as the four fp32
+//       MFMAs it replaces), fp32 accumulation.  HBM and LDS contents stay fp32 ("fp32 master" tensors).
+template <int BM, int BN, int WM, int WN, int AM, int BMD, int PRO, int NSTAGE = 2, int PREC = 0>
 __global__ __launch_bounds__(256) void dj_igemm_fast_kernel(const DjIgemmParams p) {
   using Cfg = DjIgemmCfg<BM, BN, WM, WN, AM, BMD>;
   constexpr int TM = Cfg::TM, TN = Cfg::TN, NA = Cfg::NA, NB = Cfg::NB;
@@ -311,7 +326,28 @@ __global__ __launch_bounds__(256) void dj_igemm_fast_kernel(const DjIgemmParams 
     }
   };
   auto mma = [&](const Frag& f) {
-    if (DUAL) {
+    if (PREC == 1) {
+      dj_half4 ah[TM], bh[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) ah[i] = dj_to_half4(f.a[i]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bh[j] = dj_to_half4(f.b[j]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+    } else if (PREC == 2) {
+      dj_short4 ah[TM], bh[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) ah[i] = dj_to_bf16x4(f.a[i]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bh[j] = dj_to_bf16x4(f.b[j]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ah[i], bh[j], acc[i][j], 0, 0, 0);
+    } else if (DUAL) {
 #pragma unroll
       for (int e = 0; e < 4; e += 2) {
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[0][e], f.b[0][e], acc[0][0], 0, 0, 0);

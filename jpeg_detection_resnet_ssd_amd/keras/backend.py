@@ -22,8 +22,25 @@ def image_data_format():
     return "channels_last"
 
 
+_FLOATX = {0: "float32", 1: "float16", 2: "bfloat16"}
+
+
 def floatx():
-    return "float32"
+    """'float32' (default), or the reduced-precision MFMA mode set by `set_floatx`."""
+    from .. import _lib
+    return _FLOATX[_lib.load().dj_get_compute_mode()]
+
+
+def set_floatx(value):
+    """`K.set_floatx('float16')` selects the mixed-precision convolution arithmetic of BASELINE config 5: forward GEMMs
+    on fp16 MFMA, gradient GEMMs on bf16 MFMA, fp32 accumulation; weights, activations, gradients and optimizer state
+    stay fp32 tensors (unlike Keras, which would also store float16 variables).  'bfloat16': bf16 in every GEMM.
+    'float32' restores the exact-fp32 MFMA path every 1e-3 parity claim refers to."""
+    from .. import _lib
+    modes = {v: k for k, v in _FLOATX.items()}
+    if value not in modes:
+        raise ValueError("Unknown floatx type: " + str(value))
+    _lib.load().dj_set_compute_mode(modes[value])
 
 
 def get_uid(prefix=""):
