@@ -23,7 +23,7 @@ extern "C" int dj_abi_version(void) { return 1; }
 struct TileCfg {
   int bm, bn;
 };
-static const TileCfg kCfgs[] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {128, 128}, {128, 64}, {64, 64}, {64, 64}, {128, 64}, {128, 128}, {128, 64}, {64, 64}};
+static const TileCfg kCfgs[] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {128, 128}, {128, 64}, {64, 64}, {64, 64}, {128, 64}, {128, 128}, {128, 64}, {64, 64}, {64, 64}, {128, 64}};
 // *_S1: same tile with a single LDS stage; *_S1P: single stage with loads two K-steps ahead; *_P: two stages with
 // the pinned-load / read-ahead schedule (fast kernel only; the generic kernel ignores the distinction)
 enum {
@@ -39,12 +39,14 @@ enum {
   CFG_128x128_P,
   CFG_128x64_P,
   CFG_64x64_P,
+  CFG_64x64_PK2,
+  CFG_128x64_PK2,
   N_CFG
 };
 
 template <typename KernT>
 static int launch_kernel(KernT kern, int smem_bytes, int bm, int bn, const DjIgemmParams& p, int splits, hipStream_t s,
-                         bool* attr_done) {
+                         bool* attr_done, int threads = 256) {
   if (!*attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     if (e != hipSuccess) {
@@ -55,7 +57,7 @@ static int launch_kernel(KernT kern, int smem_bytes, int bm, int bn, const DjIge
   }
   int tiles_m = dj_cdiv(p.M, bm), tiles_n = dj_cdiv(p.N, bn);
   dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)splits);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem_bytes, s, p);
+  hipLaunchKernelGGL(kern, grid, dim3(threads), smem_bytes, s, p);
   DJ_CHECK_LAUNCH("dj_igemm_kernel");
   return DJ_OK;
 }
@@ -73,6 +75,18 @@ static int launch_one(const DjIgemmParams& p, int splits, hipStream_t s, int fas
     return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 1, NSTAGE>, smem_fast, BM, BN, p, splits, s,
                          &done[2]);
   return launch_kernel(dj_igemm_kernel<BM, BN, WM, WN, AM, BMD>, Cfg::SMEM_BYTES, BM, BN, p, splits, s, &done[0]);
+}
+
+// two K groups per workgroup: pipelined schedule, 512 threads, two LDS rings
+template <int BM, int BN, int AM, int BMD>
+static int launch_k2(const DjIgemmParams& p, int splits, hipStream_t s, int fast) {
+  using Cfg = DjIgemmCfg<BM, BN, 2, 2, AM, BMD>;
+  static bool done[2] = {false, false};
+  if (fast == 1)
+    return launch_kernel(dj_igemm_fast_kernel<BM, BN, 2, 2, AM, BMD, 0, 4, 0, 2>, 2 * Cfg::SMEM_BYTES, BM, BN, p, splits, s,
+                         &done[0], 512);
+  return launch_kernel(dj_igemm_fast_kernel<BM, BN, 2, 2, AM, BMD, 1, 4, 0, 2>, 2 * Cfg::SMEM_BYTES, BM, BN, p, splits, s,
+                       &done[1], 512);
 }
 
 static bool g_allow_fast = true;
@@ -159,6 +173,11 @@ static int launch_cfg(int cfg, const DjIgemmParams& p, int splits, hipStream_t s
     case CFG_64x64_P:
       return fast ? launch_one<64, 64, 2, 2, AM, BMD, 4>(p, splits, s, fast)
                   : launch_one<64, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);
+    case CFG_64x64_PK2:
+      return fast ? launch_k2<64, 64, AM, BMD>(p, splits, s, fast) : launch_one<64, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);
+    case CFG_128x64_PK2:
+      return fast ? launch_k2<128, 64, AM, BMD>(p, splits, s, fast)
+                  : launch_one<128, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);
   }
   dj_set_error("bad tile cfg %d", cfg);
   return DJ_ERR_ARG;

@@ -44,15 +44,21 @@ __device__ __forceinline__ dj_short4 dj_to_bf16x4(f32x4 v) {
 // PREC: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1 = operands rounded to fp16, 2 = to bf16 when the fragments
 //       are read, one v_mfma_f32_32x32x8_{f16,bf16} per 8-deep k group (same lane <-> k mapping as the four fp32
 //       MFMAs it replaces), fp32 accumulation.  HBM and LDS contents stay fp32 ("fp32 master" tensors).
-template <int BM, int BN, int WM, int WN, int AM, int BMD, int PRO, int NSTAGE = 2, int PREC = 0>
-__global__ __launch_bounds__(256) void dj_igemm_fast_kernel(const DjIgemmParams p) {
+// KS: 1, or 2 = two 256-thread groups per workgroup, each with its own LDS ring, take alternate K-steps of the SAME
+//       output tile and add their accumulators through LDS before the epilogue: twice the waves per SIMD for launches
+//       that have too few tiles to fill the CUs (19x19 and 10x10 maps at batch 32), no atomics, BN statistics intact.
+template <int BM, int BN, int WM, int WN, int AM, int BMD, int PRO, int NSTAGE = 2, int PREC = 0, int KS = 1>
+__global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmParams p) {
   using Cfg = DjIgemmCfg<BM, BN, WM, WN, AM, BMD>;
   constexpr int TM = Cfg::TM, TN = Cfg::TN, NA = Cfg::NA, NB = Cfg::NB;
   constexpr int LDA_S = Cfg::LDA_S, LDB_S = Cfg::LDB_S;
   constexpr int STAGE = Cfg::STAGE_FLOATS, AFL = Cfg::A_FLOATS;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  extern __shared__ __attribute__((aligned(16))) float smem_base[];
+  static_assert(KS == 1 || NSTAGE == 4, "the K-split groups use the pipelined two-stage schedule");
 
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x & 255;
+  const int kg = (KS > 1) ? (int)(threadIdx.x >> 8) : 0;   // K group of this thread
+  float* const smem = smem_base + kg * (2 * STAGE);        // each group owns one two-stage ring
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -71,9 +77,15 @@ __global__ __launch_bounds__(256) void dj_igemm_fast_kernel(const DjIgemmParams 
   const int tile_m = tile_id / tiles_n;
   const int tile_n = tile_id - tile_m * tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int kbeg = blockIdx.y * p.kchunk;
-  const int kend = min(p.K, kbeg + p.kchunk);
-  const int nk = (kend - kbeg + DJ_BK - 1) / DJ_BK;
+  const int kbeg0 = blockIdx.y * p.kchunk;
+  const int kend = min(p.K, kbeg0 + p.kchunk);
+  const int nk_all = (kend - kbeg0 + DJ_BK - 1) / DJ_BK;
+  // group kg takes K-steps kg, kg + KS, ...; every group runs the same number of loop iterations (barriers match),
+  // iterations past a group's last tile load nothing (out-of-range offsets) and multiply zeros
+  const int kbeg = kbeg0 + kg * DJ_BK;
+  constexpr int KSTEP = KS * DJ_BK;
+  const int nk_live = (nk_all + KS - 1 - kg) / KS;
+  const int nk = (nk_all + KS - 1) / KS;
 
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
@@ -228,16 +240,19 @@ __global__ __launch_bounds__(256) void dj_igemm_fast_kernel(const DjIgemmParams 
 #pragma unroll
       for (int j = 0; j < NB; ++j) rb[j] = dj_buf_ld4(rB, (live && b_ok[j]) ? (unsigned)b_off[j] + base : DJ_OOB);
     }
-    // advance the uniform tap state to the next K-step
+    // advance the uniform tap state to this group's next K-step
     if (AM != 2 || BMD == 1) {
-      t_c0 += DJ_BK;
-      const int wrap = (t_c0 >= p.srcC) ? 1 : 0;
-      t_c0 = wrap ? 0 : t_c0;
-      t_tap += wrap;
-      t_kw += wrap;
-      const int wrap2 = (t_kw >= p.KW) ? 1 : 0;
-      t_kw = wrap2 ? 0 : t_kw;
-      t_kh += wrap2;
+#pragma unroll
+      for (int a = 0; a < KS; ++a) {
+        t_c0 += DJ_BK;
+        const int wrap = (t_c0 >= p.srcC) ? 1 : 0;
+        t_c0 = wrap ? 0 : t_c0;
+        t_tap += wrap;
+        t_kw += wrap;
+        const int wrap2 = (t_kw >= p.KW) ? 1 : 0;
+        t_kw = wrap2 ? 0 : t_kw;
+        t_kh += wrap2;
+      }
     }
   };
 
@@ -385,7 +400,7 @@ __global__ __launch_bounds__(256) void dj_igemm_fast_kernel(const DjIgemmParams 
     float* nxtB = nxtA + AFL;
     // the loads of a non-existent next tile are issued with out-of-range offsets (they return zeros
     // without touching memory) so that the K-step stays one straight-line block
-    issue_loads(r0, kbeg + (kt + 1) * DJ_BK, kt + 1 < nk);
+    issue_loads(r0, kbeg + (kt + 1) * KSTEP, kt + 1 < nk_live);
     if (NSTAGE == 4) {
       __builtin_amdgcn_sched_barrier(0);
       read_frag(F1, curA, curB, 1);
@@ -411,7 +426,7 @@ __global__ __launch_bounds__(256) void dj_igemm_fast_kernel(const DjIgemmParams 
     }
   };
 
-  issue_loads(r0, kbeg, nk > 0);
+  issue_loads(r0, kbeg, nk_live > 0);
   transform(r0);
   store_tiles(r0, smem, smem + AFL);
   __syncthreads();
@@ -469,5 +484,30 @@ __global__ __launch_bounds__(256) void dj_igemm_fast_kernel(const DjIgemmParams 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] += acc_odd[r];
   }
-  dj_igemm_epilogue<BM, BN, WM, WN>(p, acc, smem, tile_m, m0, n0);
+  if (KS > 1) {
+    // group 1 hands its partial tile to group 0 through its own (now idle) LDS ring: [value][thread], conflict-free
+    __syncthreads();
+    float* red = smem_base + 2 * STAGE;
+    static_assert(KS == 1 || TM * TN * 16 * 256 <= 2 * STAGE, "partial tile does not fit the idle LDS ring");
+    if (kg == 1) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((i * TN + j) * 16 + r) * 256 + tid] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (kg == 1) {
+      if (p.stats) __syncthreads();   // matches the one barrier of the statistics epilogue
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * TN + j) * 16 + r) * 256 + tid];
+  }
+  dj_igemm_epilogue<BM, BN, WM, WN>(p, acc, smem_base, tile_m, m0, n0);
 }

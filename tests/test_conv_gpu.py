@@ -156,3 +156,57 @@ def test_conv_transpose_via_dgrad(cuda):
     K.conv2d_dgrad(desc, x.to(cuda), kern.to(cuda), ybuf[..., 64:128], bias=bias.to(cuda))
     torch.cuda.synchronize()
     assert (ybuf[..., 64:128].cpu().double() - yr).abs().max() <= _tol(yr)
+
+
+VARIANT_CASES = [
+    (3, 19, 19, 96, 128, 3, 1, "same", 1),      # K = 27 K-steps (odd: the K groups of the *_PK2 variants get 14 / 13)
+    (2, 10, 10, 64, 192, 1, 1, "valid", 1),     # K = 2 K-steps, N = 1.5 tiles of 128
+    (2, 38, 38, 32, 64, 2, 1, "same", 1),       # one K-step per tap (srcC = 32), asymmetric padding
+]
+
+
+@pytest.mark.parametrize("case", VARIANT_CASES)
+def test_every_tile_variant(case, cuda):
+    """Each tile / schedule variant the tuner may register (dj_conv2d_tune_set), in the three directions, with the BN
+    prologue and the statistics epilogue, with and without split-K."""
+    from jpeg_detection_resnet_ssd_amd import _lib
+    from jpeg_detection_resnet_ssd_amd import kernels as K
+    lib = _lib.load()
+    b, h, w, ci, co, kk, ss, pad, dd = _geometry(case)
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(b, h, w, ci, generator=g)
+    wt = torch.randn(kk[0], kk[1], ci, co, generator=g) * (2.0 / (kk[0] * kk[1] * ci)) ** 0.5
+    bias = torch.randn(co, generator=g)
+    sc, sh = torch.rand(ci, generator=g) + 0.5, torch.randn(ci, generator=g)
+    xa = torch.relu(x * sc + sh)                                   # what the prologue feeds the GEMM
+    xr, wr = xa.double().requires_grad_(True), wt.double().requires_grad_(True)
+    yr = _oracle_conv(xr, wr, bias.double(), case)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+    y_nobias = (yr.detach() - bias.double()).reshape(-1, co)
+    desc = K.make_conv_desc(b, h, w, ci, co, kk, ss, pad, dd)
+    xd, wd, bd, dyd, scd, shd = (t.to(cuda) for t in (x, wt, bias, dy, sc, sh))
+    rows = K.conv2d_stats_rows(desc)
+    for cfg in range(lib.dj_conv2d_tune_configs()):
+        for splits in (1, 3):
+            # forward with prologue + statistics (no split-K there), dgrad of the same geometry, wgrad with prologue
+            y = torch.empty(yr.shape, device=cuda)
+            stats = torch.zeros(rows, 2, co, device=cuda)
+            _lib.check(lib.dj_conv2d_tune_set(4, desc, cfg, 1), "tune_set")
+            K.conv2d_fwd(desc, xd, wd, bd, y, scd, shd, True, False, stats)
+            dx = torch.empty(x.shape, device=cuda)
+            _lib.check(lib.dj_conv2d_tune_set(1, desc, cfg, splits), "tune_set")
+            K.conv2d_dgrad(desc, dyd, wd, dx)
+            dw = torch.zeros(wt.shape, device=cuda)
+            _lib.check(lib.dj_conv2d_tune_set(2, desc, cfg, splits), "tune_set")
+            K.conv2d_wgrad(desc, xd, dyd, dw, scd, shd, True)
+            torch.cuda.synchronize()
+            tag = "cfg %d splits %d" % (cfg, splits)
+            assert (y.cpu().double() - yr.detach()).abs().max() <= _tol(yr.detach()), tag
+            s = stats.cpu().double()
+            assert (s[:, 0].sum(0) - y_nobias.sum(0)).abs().max() <= 1e-3 * float(y_nobias.sum(0).abs().max()) + 1e-3, tag
+            assert (s[:, 1].sum(0) - (y_nobias ** 2).sum(0)).abs().max() <= 1e-3 * float((y_nobias ** 2).sum(0).max()), tag
+            assert (dx.cpu().double() - xr.grad).abs().max() <= _tol(xr.grad), tag
+            assert (dw.cpu().double() - wr.grad).abs().max() <= _tol(wr.grad), tag
+    for direction in (4, 1, 2):
+        _lib.check(lib.dj_conv2d_tune_set(direction, desc, -1, 1), "tune_set")
