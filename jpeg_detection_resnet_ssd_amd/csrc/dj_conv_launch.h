@@ -1,0 +1,166 @@
+// Tile variants of the implicit-GEMM convolution and their launchers.  dj_launch_cfg<AM, BMD> is instantiated once per
+// GEMM role in its own translation unit (dj_conv_i*.hip) so that the ~100 kernel instantiations compile in parallel.
+#pragma once
+#include "../../include/dj_hip.h"
+#include "dj_igemm.h"
+#include "dj_igemm_fast.h"
+
+// ---------------------------------------------------------------------------------
+// tile configurations
+// ---------------------------------------------------------------------------------
+struct TileCfg {
+  int bm, bn;
+};
+static const TileCfg kCfgs[] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {128, 128}, {128, 64}, {64, 64}, {64, 64}, {128, 64}, {128, 128}, {128, 64}, {64, 64}, {64, 64}, {128, 64}};
+// *_S1: same tile with a single LDS stage; *_S1P: single stage with loads two K-steps ahead; *_P: two stages with
+// the pinned-load / read-ahead schedule (fast kernel only; the generic kernel ignores the distinction)
+enum {
+  CFG_128x128 = 0,
+  CFG_128x64,
+  CFG_64x64,
+  CFG_128x32,
+  CFG_128x128_S1,
+  CFG_128x64_S1,
+  CFG_64x64_S1,
+  CFG_64x64_S1P,
+  CFG_128x64_S1P,
+  CFG_128x128_P,
+  CFG_128x64_P,
+  CFG_64x64_P,
+  CFG_64x64_PK2,
+  CFG_128x64_PK2,
+  N_CFG
+};
+
+template <typename KernT>
+static int launch_kernel(KernT kern, int smem_bytes, int bm, int bn, const DjIgemmParams& p, int splits, hipStream_t s,
+                         bool* attr_done, int threads = 256) {
+  if (!*attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    if (e != hipSuccess) {
+      dj_set_error("hipFuncSetAttribute(%d B LDS): %s", smem_bytes, hipGetErrorString(e));
+      return DJ_ERR_HIP;
+    }
+    *attr_done = true;
+  }
+  int tiles_m = dj_cdiv(p.M, bm), tiles_n = dj_cdiv(p.N, bn);
+  dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)splits);
+  hipLaunchKernelGGL(kern, grid, dim3(threads), smem_bytes, s, p);
+  DJ_CHECK_LAUNCH("dj_igemm_kernel");
+  return DJ_OK;
+}
+
+// fast = 0: generic kernel; 1: branch-free kernel; 2: branch-free kernel with the affine prologue
+template <int BM, int BN, int WM, int WN, int AM, int BMD, int NSTAGE>
+static int launch_one(const DjIgemmParams& p, int splits, hipStream_t s, int fast) {
+  using Cfg = DjIgemmCfg<BM, BN, WM, WN, AM, BMD>;
+  static bool done[3] = {false, false, false};
+  const int smem_fast = Cfg::SMEM_BYTES / 2 * ((NSTAGE == 2 || NSTAGE == 4) ? 2 : 1);
+  if (fast == 1)
+    return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 0, NSTAGE>, smem_fast, BM, BN, p, splits, s,
+                         &done[1]);
+  if (fast == 2)
+    return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 1, NSTAGE>, smem_fast, BM, BN, p, splits, s,
+                         &done[2]);
+  return launch_kernel(dj_igemm_kernel<BM, BN, WM, WN, AM, BMD>, Cfg::SMEM_BYTES, BM, BN, p, splits, s, &done[0]);
+}
+
+// two K groups per workgroup: pipelined schedule, 512 threads, two LDS rings
+template <int BM, int BN, int AM, int BMD>
+static int launch_k2(const DjIgemmParams& p, int splits, hipStream_t s, int fast) {
+  using Cfg = DjIgemmCfg<BM, BN, 2, 2, AM, BMD>;
+  static bool done[2] = {false, false};
+  if (fast == 1)
+    return launch_kernel(dj_igemm_fast_kernel<BM, BN, 2, 2, AM, BMD, 0, 4, 0, 2>, 2 * Cfg::SMEM_BYTES, BM, BN, p, splits, s,
+                         &done[0], 512);
+  return launch_kernel(dj_igemm_fast_kernel<BM, BN, 2, 2, AM, BMD, 1, 4, 0, 2>, 2 * Cfg::SMEM_BYTES, BM, BN, p, splits, s,
+                       &done[1], 512);
+}
+
+extern bool g_dj_allow_fast;   // dj_conv.hip
+
+// 0: fp32 MFMA everywhere (default).  1: forward GEMMs round their operands to fp16, gradient GEMMs (dgrad, wgrad) to
+// bf16 (gradients need the exponent range); 2: bf16 everywhere.  fp32 accumulation and fp32 tensors in all modes.
+extern int g_dj_compute_mode;   // dj_conv.hip
+
+// Preconditions of dj_igemm_fast_kernel (see its header comment).
+template <int AM, int BMD>
+static int fast_mode(const DjIgemmParams& p) {
+  if (!g_dj_allow_fast || !p.vecA || !p.vecB) return 0;
+  if (p.a_bytes <= 0 || p.b_bytes <= 0) return 0;  // operand >= 2 GiB (extent overflowed int)
+  if (AM != 2 && p.srcC % 32 != 0) return 0;
+  if (AM == 1 && (p.sH != 1 || p.sW != 1)) return 0;
+  if (AM == 2 && (p.srcC % 4 != 0 || p.K >= (1 << 24))) return 0;
+  if (BMD == 0 && (p.N % 4 != 0 || p.ldb % 4 != 0)) return 0;
+  if (BMD == 1 && p.srcC % 32 != 0) return 0;
+  return p.pro_scale ? 2 : 1;
+}
+
+// reduced-precision MFMA variants exist for the two-stage 128x128 / 128x64 / 64x64 tiles of the fast kernel
+template <int BM, int BN, int AM, int BMD, int PREC>
+static int launch_lowp(const DjIgemmParams& p, int splits, hipStream_t s, int fast) {
+  using Cfg = DjIgemmCfg<BM, BN, 2, 2, AM, BMD>;
+  static bool done[2] = {false, false};
+  if (fast == 1)
+    return launch_kernel(dj_igemm_fast_kernel<BM, BN, 2, 2, AM, BMD, 0, 2, PREC>, Cfg::SMEM_BYTES, BM, BN, p, splits, s,
+                         &done[0]);
+  return launch_kernel(dj_igemm_fast_kernel<BM, BN, 2, 2, AM, BMD, 1, 2, PREC>, Cfg::SMEM_BYTES, BM, BN, p, splits, s,
+                       &done[1]);
+}
+
+template <int AM, int BMD, int PREC>
+static int launch_lowp_cfg(int cfg, const DjIgemmParams& p, int splits, hipStream_t s, int fast) {
+  const int bm = kCfgs[cfg].bm, bn = kCfgs[cfg].bn;
+  if (bm == 128 && bn == 128) return launch_lowp<128, 128, AM, BMD, PREC>(p, splits, s, fast);
+  if (bm == 128 && bn == 64) return launch_lowp<128, 64, AM, BMD, PREC>(p, splits, s, fast);
+  return launch_lowp<64, 64, AM, BMD, PREC>(p, splits, s, fast);   // 64x64 and 128x32 requests
+}
+
+template <int AM, int BMD>
+int dj_launch_cfg(int cfg, const DjIgemmParams& p, int splits, hipStream_t s) {
+  const int fast = fast_mode<AM, BMD>(p);
+  if (fast && g_dj_compute_mode != 0 && cfg >= 0 && cfg < N_CFG) {
+    // A-mode 0 with B-mode 0 is the forward GEMM; everything else carries gradients
+    const bool forward = (AM == 0 && BMD == 0);
+    if (g_dj_compute_mode == 1 && forward) return launch_lowp_cfg<AM, BMD, 1>(cfg, p, splits, s, fast);
+    return launch_lowp_cfg<AM, BMD, 2>(cfg, p, splits, s, fast);
+  }
+  switch (cfg) {
+    case CFG_128x128: return launch_one<128, 128, 2, 2, AM, BMD, 2>(p, splits, s, fast);
+    case CFG_128x64: return launch_one<128, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);
+    case CFG_64x64: return launch_one<64, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);
+    case CFG_128x32: return launch_one<128, 32, 4, 1, AM, BMD, 2>(p, splits, s, fast);
+    case CFG_128x128_S1:
+      return fast ? launch_one<128, 128, 2, 2, AM, BMD, 1>(p, splits, s, fast)
+                  : launch_one<128, 128, 2, 2, AM, BMD, 2>(p, splits, s, fast);
+    case CFG_128x64_S1:
+      return fast ? launch_one<128, 64, 2, 2, AM, BMD, 1>(p, splits, s, fast)
+                  : launch_one<128, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);
+    case CFG_64x64_S1:
+      return fast ? launch_one<64, 64, 2, 2, AM, BMD, 1>(p, splits, s, fast)
+                  : launch_one<64, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);
+    case CFG_64x64_S1P:
+      return fast ? launch_one<64, 64, 2, 2, AM, BMD, 3>(p, splits, s, fast)
+                  : launch_one<64, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);
+    case CFG_128x64_S1P:
+      return fast ? launch_one<128, 64, 2, 2, AM, BMD, 3>(p, splits, s, fast)
+                  : launch_one<128, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);
+    case CFG_128x128_P:
+      return fast ? launch_one<128, 128, 2, 2, AM, BMD, 4>(p, splits, s, fast)
+                  : launch_one<128, 128, 2, 2, AM, BMD, 2>(p, splits, s, fast);
+    case CFG_128x64_P:
+      return fast ? launch_one<128, 64, 2, 2, AM, BMD, 4>(p, splits, s, fast)
+                  : launch_one<128, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);
+    case CFG_64x64_P:
+      return fast ? launch_one<64, 64, 2, 2, AM, BMD, 4>(p, splits, s, fast)
+                  : launch_one<64, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);
+    case CFG_64x64_PK2:
+      return fast ? launch_k2<64, 64, AM, BMD>(p, splits, s, fast) : launch_one<64, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);
+    case CFG_128x64_PK2:
+      return fast ? launch_k2<128, 64, AM, BMD>(p, splits, s, fast)
+                  : launch_one<128, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);
+  }
+  dj_set_error("bad tile cfg %d", cfg);
+  return DJ_ERR_ARG;
+}
+
