@@ -34,6 +34,10 @@ def load():
         raise DjError(
             "HIP extension %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback for the compute path)" % LIB_PATH)
+    # torch first: its wheel bundles the HIP runtime (libamdhip64) the process must share -- loading this library
+    # before torch would bind it to /opt/rocm's copy instead, and kernels registered with one runtime cannot be
+    # launched on the device the other one owns ("no ROCm-capable device is detected")
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     _declare(lib)
     _lib = lib
