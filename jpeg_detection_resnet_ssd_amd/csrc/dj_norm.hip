@@ -146,34 +146,38 @@ static int launch_colreduce(F f, long rows, int C, bool vec4, float* partial, hi
 
 static inline bool al16p(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-// Column sums of the two partial slots for 32 channels per block: 1024 threads = 32 channels x 32 row
-// lanes, coalesced 128-byte reads, double accumulation.  Valid in threads with ty == 0 (c < C).
+// Column sums of the two partial slots for DJ_FIN_CH channels per block: 1024 threads = 16 channels x 64 row lanes
+// (a 38x38x256 layer has 722 partial rows but only 256 channels: few channels per block keeps 16 blocks busy and
+// 12 rows per lane), 64-byte row segments, double accumulation.  Valid in threads with ty == 0 (c < C).
 #define DJ_FIN_THREADS 1024
+#define DJ_FIN_CH 16
+#define DJ_FIN_LANES (DJ_FIN_THREADS / DJ_FIN_CH)
 __device__ __forceinline__ void dj_partial_sums(const float* partial, int nrows, int C, int which_mask, double& s0,
                                                 double& s1) {
-  __shared__ double red0[32][33];
-  __shared__ double red1[32][33];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + tx;
+  __shared__ double red0[DJ_FIN_LANES][DJ_FIN_CH + 1];
+  __shared__ double red1[DJ_FIN_LANES][DJ_FIN_CH + 1];
+  const int tx = threadIdx.x & (DJ_FIN_CH - 1), ty = threadIdx.x / DJ_FIN_CH;
+  const int c = blockIdx.x * DJ_FIN_CH + tx;
   double a = 0.0, b = 0.0;
   if (c < C) {
-    // four rows in flight per thread: the loop is latency-bound (a few dozen dependent loads otherwise)
+    // four rows in flight per thread: the loop is latency-bound (dependent loads otherwise)
     double a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0, a3 = 0.0, b3 = 0.0;
+    constexpr int L = DJ_FIN_LANES;
     int r = ty;
-    for (; r + 96 < nrows; r += 128) {
+    for (; r + 3 * L < nrows; r += 4 * L) {
       const float* p = partial + (size_t)r * 2 * C + c;
       float x0 = 0.f, x1 = 0.f, x2 = 0.f, x3 = 0.f, y0 = 0.f, y1 = 0.f, y2 = 0.f, y3 = 0.f;
       if (which_mask & 1) {
         x0 = p[0];
-        x1 = p[(size_t)64 * C];
-        x2 = p[(size_t)128 * C];
-        x3 = p[(size_t)192 * C];
+        x1 = p[(size_t)(2 * L) * C];
+        x2 = p[(size_t)(4 * L) * C];
+        x3 = p[(size_t)(6 * L) * C];
       }
       if (which_mask & 2) {
         y0 = p[C];
-        y1 = p[(size_t)65 * C];
-        y2 = p[(size_t)129 * C];
-        y3 = p[(size_t)193 * C];
+        y1 = p[(size_t)(2 * L + 1) * C];
+        y2 = p[(size_t)(4 * L + 1) * C];
+        y3 = p[(size_t)(6 * L + 1) * C];
       }
       a += (double)x0;
       a1 += (double)x1;
@@ -184,7 +188,7 @@ __device__ __forceinline__ void dj_partial_sums(const float* partial, int nrows,
       b2 += (double)y2;
       b3 += (double)y3;
     }
-    for (; r < nrows; r += 32) {
+    for (; r < nrows; r += L) {
       if (which_mask & 1) a += (double)partial[((size_t)r * 2 + 0) * C + c];
       if (which_mask & 2) b += (double)partial[((size_t)r * 2 + 1) * C + c];
     }
@@ -194,8 +198,17 @@ __device__ __forceinline__ void dj_partial_sums(const float* partial, int nrows,
   red0[ty][tx] = a;
   red1[ty][tx] = b;
   __syncthreads();
+  if (ty < 8) {   // two-level: 8 lanes fold 8 rows each, then lane 0 folds those
+    for (int j = ty + 8; j < DJ_FIN_LANES; j += 8) {
+      a += red0[j][tx];
+      b += red1[j][tx];
+    }
+    red0[ty][tx] = a;
+    red1[ty][tx] = b;
+  }
+  __syncthreads();
   if (ty == 0) {
-    for (int j = 1; j < 32; ++j) {
+    for (int j = 1; j < 8; ++j) {
       a += red0[j][tx];
       b += red1[j][tx];
     }
@@ -225,8 +238,8 @@ __global__ __launch_bounds__(DJ_FIN_THREADS) void dj_colreduce_finalize_kernel(c
                                                                                int which, float* out, int beta) {
   double s0, s1;
   dj_partial_sums(partial, nrows, C, which == 0 ? 1 : 2, s0, s1);
-  int c = blockIdx.x * 32 + (threadIdx.x & 31);
-  if ((threadIdx.x >> 5) != 0 || c >= C) return;
+  int c = blockIdx.x * DJ_FIN_CH + (threadIdx.x & (DJ_FIN_CH - 1));
+  if ((threadIdx.x / DJ_FIN_CH) != 0 || c >= C) return;
   float v = (float)(which == 0 ? s0 : s1);
   if (beta) v += out[c];
   out[c] = v;
@@ -235,7 +248,7 @@ __global__ __launch_bounds__(DJ_FIN_THREADS) void dj_colreduce_finalize_kernel(c
 extern "C" int dj_colreduce_finalize(const float* partial, int nrows, int C, int which, float* out, int beta,
                                      void* stream) {
   DJ_CHECK_ARG(partial && out && nrows > 0 && C > 0 && (which == 0 || which == 1), "colreduce_finalize: bad arguments");
-  hipLaunchKernelGGL(dj_colreduce_finalize_kernel, dim3(dj_cdiv(C, 32)), dim3(DJ_FIN_THREADS), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(dj_colreduce_finalize_kernel, dim3(dj_cdiv(C, DJ_FIN_CH)), dim3(DJ_FIN_THREADS), 0, (hipStream_t)stream,
                      partial, nrows, C, which, out, beta);
   DJ_CHECK_LAUNCH("dj_colreduce_finalize");
   return DJ_OK;
@@ -250,8 +263,8 @@ __global__ __launch_bounds__(DJ_FIN_THREADS) void dj_bn_train_finalize_kernel(co
                                             float* save_mean, float* save_invstd, int C) {
   double s, q;
   dj_partial_sums(partial, nrows, C, 3, s, q);
-  int c = blockIdx.x * 32 + (threadIdx.x & 31);
-  if ((threadIdx.x >> 5) != 0 || c >= C) return;
+  int c = blockIdx.x * DJ_FIN_CH + (threadIdx.x & (DJ_FIN_CH - 1));
+  if ((threadIdx.x / DJ_FIN_CH) != 0 || c >= C) return;
   double m = s / count;
   double var = q / count - m * m;
   if (var < 0.0) var = 0.0;
@@ -277,7 +290,7 @@ extern "C" int dj_bn_train_finalize(const float* partial, int nrows, long count,
   DJ_CHECK_ARG(partial && gamma && beta && scale && shift && save_mean && save_invstd, "bn_train_finalize: null");
   DJ_CHECK_ARG(nrows > 0 && count > 0 && C > 0, "bn_train_finalize: bad sizes");
   DJ_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "bn_train_finalize: moving stats come together");
-  hipLaunchKernelGGL(dj_bn_train_finalize_kernel, dim3(dj_cdiv(C, 32)), dim3(DJ_FIN_THREADS), 0, (hipStream_t)stream, partial,
+  hipLaunchKernelGGL(dj_bn_train_finalize_kernel, dim3(dj_cdiv(C, DJ_FIN_CH)), dim3(DJ_FIN_THREADS), 0, (hipStream_t)stream, partial,
                      nrows, (double)count, conv_bias, gamma, beta, eps, momentum, moving_mean, moving_var, scale,
                      shift, save_mean, save_invstd, C);
   DJ_CHECK_LAUNCH("dj_bn_train_finalize");
@@ -383,8 +396,8 @@ __global__ __launch_bounds__(DJ_FIN_THREADS) void dj_bn_bwd_finalize_kernel(cons
                                           float* k0, float* k1, float* k2, int C) {
   double sb, sg;
   dj_partial_sums(partial, nrows, C, 3, sb, sg);
-  int c = blockIdx.x * 32 + (threadIdx.x & 31);
-  if ((threadIdx.x >> 5) != 0 || c >= C) return;
+  int c = blockIdx.x * DJ_FIN_CH + (threadIdx.x & (DJ_FIN_CH - 1));
+  if ((threadIdx.x / DJ_FIN_CH) != 0 || c >= C) return;
   dbeta[c] = (float)sb;
   dgamma[c] = (float)sg;
   double is = (double)invstd[c], sc = (double)gamma[c] * is;
@@ -399,7 +412,7 @@ extern "C" int dj_bn_bwd_finalize(const float* partial, int nrows, long count, c
                                   int C, void* stream) {
   DJ_CHECK_ARG(partial && gamma && mean && invstd && dgamma && dbeta && k0 && k1 && k2, "bn_bwd_finalize: null");
   DJ_CHECK_ARG(nrows > 0 && count > 0 && C > 0, "bn_bwd_finalize: bad sizes");
-  hipLaunchKernelGGL(dj_bn_bwd_finalize_kernel, dim3(dj_cdiv(C, 32)), dim3(DJ_FIN_THREADS), 0, (hipStream_t)stream, partial,
+  hipLaunchKernelGGL(dj_bn_bwd_finalize_kernel, dim3(dj_cdiv(C, DJ_FIN_CH)), dim3(DJ_FIN_THREADS), 0, (hipStream_t)stream, partial,
                      nrows, (double)count, gamma, mean, invstd, dgamma, dbeta, k0, k1, k2, C);
   DJ_CHECK_LAUNCH("dj_bn_bwd_finalize");
   return DJ_OK;
