@@ -12,6 +12,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The C-ABI libraries are build products (git-ignored): a fresh checkout compiles them once (hipcc cross-compiles
+    gfx950 without a GPU, about a minute); an existing build is left alone."""
+    from jpeg_detection_resnet_ssd_amd import _build
+    if not (os.path.exists(_build.LIB_PATH) and os.path.exists(_build.JPEG_LIB_PATH)):
+        _build.build_library()
+
+
 @pytest.fixture(scope="session")
 def cuda():
     import torch
