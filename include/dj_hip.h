@@ -191,6 +191,14 @@ int dj_decode_detections(const float* y_pred, int batch, int n_boxes, int n_clas
                          float iou_threshold, int top_k, int nms_max_output_size, int normalize_coords, int img_height,
                          int img_width, float* workspace, float* out, void* stream);
 
+/* ---- DecodeDetectionsFast (L/keras_layers/keras_layer_DecodeDetectionsFast.py:108-215, mode='inference_fast'): each box
+ * keeps its arg-max class and that confidence, background boxes are dropped, threshold, ONE class-agnostic greedy NMS
+ * (at most nms_max_output_size <= 8192), top-k.  Same tensors and output layout as dj_decode_detections. ---- */
+long dj_decode_detections_fast_workspace_floats(int batch, int n_boxes, int nms_max_output_size);
+int dj_decode_detections_fast(const float* y_pred, int batch, int n_boxes, int n_classes, float confidence_thresh,
+                              float iou_threshold, int top_k, int nms_max_output_size, int normalize_coords,
+                              int img_height, int img_width, float* workspace, float* out, void* stream);
+
 /* ---- SSDInputEncoder.__call__ for coords='centroids' (L/ssd_encoder_decoder/ssd_input_encoder.py:277-418,
  * matching_utils.py:22-116, L/bounding_box_utils/bounding_box_utils.py:283-383): labels [batch][max_gt][5] =
  * (class id, xmin, ymin, xmax, ymax) in pixels (float64, as the reference computes), n_gt [batch] valid rows,

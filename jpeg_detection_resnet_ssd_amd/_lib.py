@@ -88,6 +88,9 @@ SIGNATURES = {
     "dj_decode_detections_workspace_floats": (c_long, [c_int, c_int, c_int, c_int]),
     "dj_decode_detections": (c_int, [FP, c_int, c_int, c_int, c_float, c_float, c_int, c_int, c_int, c_int, c_int, FP, FP,
                                      c_void_p]),
+    "dj_decode_detections_fast_workspace_floats": (c_long, [c_int, c_int, c_int]),
+    "dj_decode_detections_fast": (c_int, [FP, c_int, c_int, c_int, c_float, c_float, c_int, c_int, c_int, c_int, c_int, FP, FP,
+                                          c_void_p]),
     "dj_ssd_encode_targets": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_int, c_double, c_double, c_int, FP, c_void_p]),
     "dj_global_avg_pool_fwd": (c_int, [FP, FP, c_int, c_int, c_int, c_void_p]),

@@ -23,9 +23,11 @@ __global__ __launch_bounds__(256) void dj_decode_boxes_kernel(const float* y_pre
 
 // one workgroup per (class, image): greedy NMS in descending score order (ties: lowest box index), a box is
 // dropped when IoU > iou_thresh with a kept one; at most max_out kept.  kept rows: [class, conf, xmin, ymin, xmax, ymax]
+// fast_score / fast_class (DecodeDetectionsFast): per-box score and class id instead of one class column of y_pred
 __global__ __launch_bounds__(256) void dj_nms_class_kernel(const float* y_pred, const f32x4* boxes, int N, int width,
                                                             float conf_thresh, float iou_thresh, int max_out,
-                                                            float* kept, int* counts) {
+                                                            float* kept, int* counts, const float* fast_score,
+                                                            const float* fast_class) {
   __shared__ float score[DJ_NMS_CAP];
   __shared__ float wmax[4];
   __shared__ int widx[4];
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(256) void dj_nms_class_kernel(const float* y_pred, 
   const float* yp = y_pred + (size_t)img * N * width;
   const f32x4* bx = boxes + (size_t)img * N;
   for (int i = tid; i < N; i += 256) {
-    float s = yp[(size_t)i * width + cls];
+    float s = fast_score ? fast_score[(size_t)img * N + i] : yp[(size_t)i * width + cls];
     score[i] = (s > conf_thresh) ? s : -1.f;
   }
   __syncthreads();
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256) void dj_nms_class_kernel(const float* y_pred, 
     const f32x4 bb = bx[best];
     if (tid == 0) {
       float* o = out + (size_t)nk * 6;
-      o[0] = (float)cls;
+      o[0] = fast_class ? fast_class[(size_t)img * N + best] : (float)cls;
       o[1] = score[best];
       o[2] = bb.x;
       o[3] = bb.y;
@@ -185,10 +187,67 @@ extern "C" int dj_decode_detections(const float* y_pred, int batch, int n_boxes,
   hipLaunchKernelGGL(dj_decode_boxes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, y_pred, nbox, width, sx, sy, boxes);
   DJ_CHECK_LAUNCH("dj_decode_boxes");
   hipLaunchKernelGGL(dj_nms_class_kernel, dim3(n_fg, batch), dim3(256), 0, s, y_pred, boxes, n_boxes, width,
-                     confidence_thresh, iou_threshold, nms_max_output_size, kept, counts);
+                     confidence_thresh, iou_threshold, nms_max_output_size, kept, counts, (const float*)nullptr,
+                     (const float*)nullptr);
   DJ_CHECK_LAUNCH("dj_nms_class");
   hipLaunchKernelGGL(dj_topk_merge_kernel, dim3(batch), dim3(1024), 0, s, kept, counts, n_fg, nms_max_output_size, top_k,
                      out);
+  DJ_CHECK_LAUNCH("dj_topk_merge");
+  return DJ_OK;
+}
+
+// ---- DecodeDetectionsFast (localisation_part/keras_layers/keras_layer_DecodeDetectionsFast.py:108-215): every box keeps
+// only its arg-max class (tf.argmax: first maximum) and that confidence; background boxes are dropped, the rest is
+// thresholded, ONE class-agnostic NMS, top-k.
+__global__ __launch_bounds__(256) void dj_decode_fast_prep_kernel(const float* y_pred, long nbox, int width, int n_classes,
+                                                                   float* score, float* cls) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nbox; i += (long)gridDim.x * 256) {
+    const float* p = y_pred + i * width;
+    float m = p[0];
+    int mi = 0;
+    for (int c = 1; c < n_classes; ++c)
+      if (p[c] > m) {
+        m = p[c];
+        mi = c;
+      }
+    score[i] = (mi != 0) ? m : -1.f;   // class 0 = background: never a detection
+    cls[i] = (float)mi;
+  }
+}
+
+extern "C" long dj_decode_detections_fast_workspace_floats(int batch, int n_boxes, int nms_max_output_size) {
+  return (long)batch * n_boxes * 6 + (long)batch * nms_max_output_size * 6 + batch + 16;
+}
+
+extern "C" int dj_decode_detections_fast(const float* y_pred, int batch, int n_boxes, int n_classes,
+                                         float confidence_thresh, float iou_threshold, int top_k, int nms_max_output_size,
+                                         int normalize_coords, int img_height, int img_width, float* workspace, float* out,
+                                         void* stream) {
+  DJ_CHECK_ARG(y_pred && workspace && out, "decode_detections_fast: null tensor");
+  DJ_CHECK_ARG(batch > 0 && n_boxes > 0 && n_classes > 1 && top_k > 0 && nms_max_output_size > 0,
+               "decode_detections_fast: bad sizes");
+  DJ_CHECK_ARG(n_boxes <= DJ_NMS_CAP, "decode_detections_fast: more than %d boxes per image", DJ_NMS_CAP);
+  DJ_CHECK_ARG(nms_max_output_size <= DJ_TOPK_CAP, "decode_detections_fast: nms_max_output_size exceeds %d", DJ_TOPK_CAP);
+  hipStream_t s = (hipStream_t)stream;
+  const int width = n_classes + 12;
+  const long nbox = (long)batch * n_boxes;
+  f32x4* boxes = reinterpret_cast<f32x4*>(workspace);
+  float* score = workspace + nbox * 4;
+  float* cls = score + nbox;
+  float* kept = cls + nbox;
+  int* counts = reinterpret_cast<int*>(kept + (size_t)batch * nms_max_output_size * 6);
+  const float sx = normalize_coords ? (float)img_width : 1.f, sy = normalize_coords ? (float)img_height : 1.f;
+  long blocks = (nbox + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(dj_decode_boxes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, y_pred, nbox, width, sx, sy, boxes);
+  DJ_CHECK_LAUNCH("dj_decode_boxes");
+  hipLaunchKernelGGL(dj_decode_fast_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, s, y_pred, nbox, width, n_classes,
+                     score, cls);
+  DJ_CHECK_LAUNCH("dj_decode_fast_prep");
+  hipLaunchKernelGGL(dj_nms_class_kernel, dim3(1, batch), dim3(256), 0, s, y_pred, boxes, n_boxes, width, confidence_thresh,
+                     iou_threshold, nms_max_output_size, kept, counts, (const float*)score, (const float*)cls);
+  DJ_CHECK_LAUNCH("dj_nms_fast");
+  hipLaunchKernelGGL(dj_topk_merge_kernel, dim3(batch), dim3(1024), 0, s, kept, counts, 1, nms_max_output_size, top_k, out);
   DJ_CHECK_LAUNCH("dj_topk_merge");
   return DJ_OK;
 }

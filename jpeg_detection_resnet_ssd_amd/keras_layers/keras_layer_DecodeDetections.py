@@ -21,9 +21,7 @@ class DecodeDetections(Layer):
                              "and `img_width == {}`".format(img_height, img_width))
         if coords != "centroids":
             raise ValueError("The DetectionOutput layer currently only supports the 'centroids' coordinate format.")
-        if fast:
-            raise NotImplementedError("mode='inference_fast' (DecodeDetectionsFast: arg-max class per box before NMS) is "
-                                      "not built; use mode='inference'")
+        self.fast = bool(fast)   # True: the DecodeDetectionsFast algorithm (arg-max class per box, one class-agnostic NMS)
         self.confidence_thresh = confidence_thresh
         self.iou_threshold = iou_threshold
         self.top_k = top_k
@@ -54,9 +52,13 @@ class DecodeDetections(Layer):
         assert yp.is_contiguous()
         b, n, width = yp.shape
         n_cls = width - 12
-        ws = plan.empty(query("dj_decode_detections_workspace_floats", b, n, n_cls, self.nms_max_output_size))
+        if self.fast:
+            ws = plan.empty(query("dj_decode_detections_fast_workspace_floats", b, n, self.nms_max_output_size))
+        else:
+            ws = plan.empty(query("dj_decode_detections_workspace_floats", b, n, n_cls, self.nms_max_output_size))
         out = plan.empty(b, self.top_k, 6)
-        plan.emit(lambda: call("dj_decode_detections", yp, b, n, n_cls, float(self.confidence_thresh),
+        entry = "dj_decode_detections_fast" if self.fast else "dj_decode_detections"
+        plan.emit(lambda: call(entry, yp, b, n, n_cls, float(self.confidence_thresh),
                                float(self.iou_threshold), int(self.top_k), int(self.nms_max_output_size),
                                int(bool(self.normalize_coords)), int(self.img_height or 0), int(self.img_width or 0), ws,
                                out))

@@ -1,6 +1,6 @@
 """Host-side (numpy) decoding of raw SSD predictions: offsets -> absolute boxes, per-class confidence threshold and
 greedy NMS, top-k.  Same function names and arguments as localisation_part/ssd_encoder_decoder/ssd_output_decoder.py
-(`greedy_nms` :27-75, `_greedy_nms` :77-92, `decode_detections` :111-226)."""
+(`greedy_nms` :27-75, `_greedy_nms` :77-92, `decode_detections` :111-226, `decode_detections_fast` :228-340)."""
 import numpy as np
 
 from ..bounding_box_utils.bounding_box_utils import convert_coordinates, iou
@@ -82,4 +82,49 @@ def decode_detections(y_pred, confidence_thresh=0.01, iou_threshold=0.45, top_k=
         else:
             pred = np.array(pred)
         out.append(pred)
+    return out
+
+
+def decode_detections_fast(y_pred, confidence_thresh=0.5, iou_threshold=0.45, top_k="all", input_coords="centroids",
+                           normalize_coords=True, img_height=None, img_width=None, border_pixels="half"):
+    """The cheaper decoder: each box keeps its arg-max class only, background boxes are dropped, then threshold,
+    one NMS over all classes together (if `iou_threshold` is given) and top-k.  -> list of (k_i, 6) arrays."""
+    if normalize_coords and ((img_height is None) or (img_width is None)):
+        raise ValueError("If relative box coordinates are supposed to be converted to absolute coordinates, the decoder "
+                         "needs the image size in order to decode the predictions, but `img_height == {}` and "
+                         "`img_width == {}`".format(img_height, img_width))
+    conv = np.copy(y_pred[:, :, -14:-8])
+    conv[:, :, 0] = np.argmax(y_pred[:, :, :-12], axis=-1)
+    conv[:, :, 1] = np.amax(y_pred[:, :, :-12], axis=-1)
+    anc, var = y_pred[:, :, -8:-4], y_pred[:, :, -4:]
+    if input_coords == "centroids":
+        conv[:, :, [4, 5]] = np.exp(conv[:, :, [4, 5]] * var[:, :, [2, 3]]) * anc[:, :, [2, 3]]
+        conv[:, :, [2, 3]] = conv[:, :, [2, 3]] * var[:, :, [0, 1]] * anc[:, :, [2, 3]] + anc[:, :, [0, 1]]
+        conv = convert_coordinates(conv, start_index=-4, conversion="centroids2corners")
+    elif input_coords == "minmax":
+        conv[:, :, 2:] *= var
+        conv[:, :, [2, 3]] *= np.expand_dims(anc[:, :, 1] - anc[:, :, 0], axis=-1)
+        conv[:, :, [4, 5]] *= np.expand_dims(anc[:, :, 3] - anc[:, :, 2], axis=-1)
+        conv[:, :, 2:] += anc
+        conv = convert_coordinates(conv, start_index=-4, conversion="minmax2corners")
+    elif input_coords == "corners":
+        conv[:, :, 2:] *= var
+        conv[:, :, [2, 4]] *= np.expand_dims(anc[:, :, 2] - anc[:, :, 0], axis=-1)
+        conv[:, :, [3, 5]] *= np.expand_dims(anc[:, :, 3] - anc[:, :, 1], axis=-1)
+        conv[:, :, 2:] += anc
+    else:
+        raise ValueError("Unexpected value for `coords`. Supported values are 'minmax', 'corners' and 'centroids'.")
+    if normalize_coords:
+        conv[:, :, [2, 4]] *= img_width
+        conv[:, :, [3, 5]] *= img_height
+    out = []
+    for item in conv:
+        boxes = item[np.nonzero(item[:, 0])]
+        boxes = boxes[boxes[:, 1] >= confidence_thresh]
+        if iou_threshold and boxes.shape[0] > 0:
+            boxes = _nms(boxes, 1, 2, iou_threshold, "corners", border_pixels)
+        if top_k != "all" and boxes.shape[0] > top_k:
+            keep = np.argpartition(boxes[:, 1], kth=boxes.shape[0] - top_k, axis=0)[boxes.shape[0] - top_k:]
+            boxes = boxes[keep]
+        out.append(boxes)
     return out

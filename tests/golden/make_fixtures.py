@@ -99,8 +99,12 @@ def decode_fixture():
                             normalize_coords=True, img_height=300, img_width=300)
     dec2 = decode_detections(y_pred.astype(np.float64), confidence_thresh=0.05, iou_threshold=0.45, top_k=50,
                              normalize_coords=True, img_height=300, img_width=300)
-    np.savez_compressed(os.path.join(OUT, "decode.npz"), y_pred=y_pred, d0=dec[0], d1=dec[1], e0=dec2[0], e1=dec2[1])
-    print("decode fixture: kept", [d.shape for d in dec], [d.shape for d in dec2])
+    from ssd_encoder_decoder.ssd_output_decoder import decode_detections_fast
+    fast = decode_detections_fast(y_pred.astype(np.float64), confidence_thresh=0.3, iou_threshold=0.45, top_k=200,
+                                  normalize_coords=True, img_height=300, img_width=300)
+    np.savez_compressed(os.path.join(OUT, "decode.npz"), y_pred=y_pred, d0=dec[0], d1=dec[1], e0=dec2[0], e1=dec2[1],
+                        f0=fast[0], f1=fast[1])
+    print("decode fixture: kept", [d.shape for d in dec], [d.shape for d in dec2], [d.shape for d in fast])
 
 
 if __name__ == "__main__":

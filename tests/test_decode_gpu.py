@@ -134,3 +134,40 @@ def test_evaluator_runs_an_inference_model_end_to_end():
         b = sorted((p[0], round(float(p[1]), 5)) for p in ev_t.prediction_results[c])
         assert a == b
     assert sum(len(r) for r in ev_i.prediction_results) == 6 * 20
+
+
+def test_decode_fast_against_reference_fixture():
+    """DecodeDetectionsFast kernels (arg-max class, one class-agnostic NMS) vs the reference's decode_detections_fast."""
+    from jpeg_detection_resnet_ssd_amd.engine import call, query
+    g = np.load(GOLD)
+    y = torch.from_numpy(g["y_pred"]).cuda().contiguous()
+    b, n, w = y.shape
+    ws = torch.empty(query("dj_decode_detections_fast_workspace_floats", b, n, 400), device="cuda")
+    out = torch.full((b, 200, 6), -7.0, device="cuda")
+    call("dj_decode_detections_fast", y, b, n, w - 12, 0.3, 0.45, 200, 400, 1, 300, 300, ws, out)
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    for i, key in enumerate(("f0", "f1")):
+        got, ref = canon(out[i]), canon(g[key])
+        assert got.shape == ref.shape
+        np.testing.assert_array_equal(got[:, 0], ref[:, 0])
+        np.testing.assert_allclose(got[:, 1], ref[:, 1], rtol=1e-6)
+        np.testing.assert_allclose(got[:, 2:], ref[:, 2:], atol=2e-2)
+        assert np.all(out[i][:-1, 1] >= out[i][1:, 1])
+
+
+def test_inference_fast_mode_model():
+    from jpeg_detection_resnet_ssd_amd import workloads
+    from jpeg_detection_resnet_ssd_amd.keras import backend as K
+    from jpeg_detection_resnet_ssd_amd.models.keras_ssd300_dct_j2d_resnet import ssd_resnet_EF_layers_identical
+    K.clear_session()
+    m = ssd_resnet_EF_layers_identical(archi="deconv", **dict(workloads.SSD_ARGS, mode="inference_fast", top_k=30))
+    assert m.layers[-1].__class__.__name__ in ("DecodeDetections", "DecodeDetectionsFast") and m.layers[-1].fast
+    w = m.get_weights_dict()
+    for k in w:                                   # random init: keep exp() of the box offsets finite
+        if "mbox_loc" in k or "mbox_conf" in k:
+            w[k] = w[k] * 1e-5
+    m.set_weights_dict(w)
+    x = workloads.synthetic_batch("deconv", [(38, 38), (10, 10), (5, 5), (5, 5), (3, 3), (1, 1)], 2, seed=3)[0]
+    det = m.predict(x, batch_size=2)
+    assert det.shape == (2, 30, 6) and np.isfinite(det).all()
