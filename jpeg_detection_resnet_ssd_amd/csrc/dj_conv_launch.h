@@ -11,7 +11,7 @@
 struct TileCfg {
   int bm, bn;
 };
-static const TileCfg kCfgs[] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {128, 128}, {128, 64}, {64, 64}, {64, 64}, {128, 64}, {128, 128}, {128, 64}, {64, 64}, {64, 64}, {128, 64}, {64, 64}, {128, 64}};
+static const TileCfg kCfgs[] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {128, 128}, {128, 64}, {64, 64}, {64, 64}, {128, 64}, {128, 128}, {128, 64}, {64, 64}, {64, 64}, {128, 64}};
 // *_S1: same tile with a single LDS stage; *_S1P: single stage with loads two K-steps ahead; *_P: two stages with
 // the pinned-load / read-ahead schedule (fast kernel only; the generic kernel ignores the distinction)
 enum {
@@ -29,8 +29,6 @@ enum {
   CFG_64x64_P,
   CFG_64x64_PK2,
   CFG_128x64_PK2,
-  CFG_64x64_P2,
-  CFG_128x64_P2,
   N_CFG
 };
 
@@ -57,7 +55,7 @@ template <int BM, int BN, int WM, int WN, int AM, int BMD, int NSTAGE>
 static int launch_one(const DjIgemmParams& p, int splits, hipStream_t s, int fast) {
   using Cfg = DjIgemmCfg<BM, BN, WM, WN, AM, BMD>;
   static bool done[3] = {false, false, false};
-  const int smem_fast = Cfg::SMEM_BYTES / 2 * ((NSTAGE == 2 || NSTAGE >= 4) ? 2 : 1);
+  const int smem_fast = Cfg::SMEM_BYTES / 2 * ((NSTAGE == 2 || NSTAGE == 4) ? 2 : 1);
   if (fast == 1)
     return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 0, NSTAGE>, smem_fast, BM, BN, p, splits, s,
                          &done[1]);
@@ -156,12 +154,6 @@ int dj_launch_cfg(int cfg, const DjIgemmParams& p, int splits, hipStream_t s) {
     case CFG_64x64_P:
       return fast ? launch_one<64, 64, 2, 2, AM, BMD, 4>(p, splits, s, fast)
                   : launch_one<64, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);
-    case CFG_64x64_P2:
-      return fast ? launch_one<64, 64, 2, 2, AM, BMD, 5>(p, splits, s, fast)
-                  : launch_one<64, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);
-    case CFG_128x64_P2:
-      return fast ? launch_one<128, 64, 2, 2, AM, BMD, 5>(p, splits, s, fast)
-                  : launch_one<128, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);
     case CFG_64x64_PK2:
       return fast ? launch_k2<64, 64, AM, BMD>(p, splits, s, fast) : launch_one<64, 64, 2, 2, AM, BMD, 2>(p, splits, s, fast);
     case CFG_128x64_PK2:

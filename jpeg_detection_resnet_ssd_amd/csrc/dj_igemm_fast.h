@@ -392,47 +392,19 @@ __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmPa
   //   the other stage, barrier, and the FIRST fragments of that stage are read BEFORE the last k group's MFMAs are
   //   issued, so the LDS latency across the step boundary hides behind them.  Wins when few workgroups share a CU.
   Frag F0, F1;
-  // NSTAGE == 5: the pipelined schedule with the loads TWO K-steps ahead (tile kt+2 is requested while tile kt+1
-  //   waits in the other register set): a load has two steps of MFMAs to land -- for launches so small that a
-  //   workgroup is alone on its CU.
   auto kstep = [&](auto stage_tag, int kt) {
     constexpr int S = decltype(stage_tag)::value;
     float* curA = smem + S * STAGE;
     float* curB = curA + AFL;
     float* nxtA = smem + (S ^ 1) * STAGE;
     float* nxtB = nxtA + AFL;
-    if (NSTAGE == 5) {
-      Regs& cur = S ? r1 : r0;    // holds tile kt+1 (requested one step ago)
-      Regs& nxt = S ? r0 : r1;    // receives tile kt+2
-      issue_loads(nxt, kbeg + (kt + 2) * KSTEP, kt + 2 < nk_live);
-      __builtin_amdgcn_sched_barrier(0);
-      read_frag(F1, curA, curB, 1);
-      mma(F0);
-      read_frag(F0, curA, curB, 2);
-      mma(F1);
-      read_frag(F1, curA, curB, 3);
-      mma(F0);
-      transform(cur);
-      store_tiles(cur, nxtA, nxtB);
-      __syncthreads();
-      read_frag(F0, nxtA, nxtB, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(F1);
-      return;
-    }
     // the loads of a non-existent next tile are issued with out-of-range offsets (they return zeros
     // without touching memory) so that the K-step stays one straight-line block
     issue_loads(r0, kbeg + (kt + 1) * KSTEP, kt + 1 < nk_live);
     if (NSTAGE == 4) {
-#ifdef DJ_EXP_INTERLEAVE
-      read_frag(F1, curA, curB, 1);
-      mma(F0);
-      __builtin_amdgcn_sched_barrier(0);   // the loads may mix with the first k group's MFMAs but not sink further
-#else
       __builtin_amdgcn_sched_barrier(0);
       read_frag(F1, curA, curB, 1);
       mma(F0);
-#endif
       read_frag(F0, curA, curB, 2);
       mma(F1);
       read_frag(F1, curA, curB, 3);
@@ -458,9 +430,8 @@ __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmPa
   transform(r0);
   store_tiles(r0, smem, smem + AFL);
   __syncthreads();
-  if (NSTAGE == 2 || NSTAGE == 4 || NSTAGE == 5) {
-    if (NSTAGE >= 4) read_frag(F0, smem, smem + AFL, 0);
-    if (NSTAGE == 5) issue_loads(r0, kbeg + KSTEP, 1 < nk_live);   // tile 1 -> r0 (stage-0 steps store r0)
+  if (NSTAGE == 2 || NSTAGE == 4) {
+    if (NSTAGE == 4) read_frag(F0, smem, smem + AFL, 0);
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) {
       kstep(std::integral_constant<int, 0>{}, kt);
