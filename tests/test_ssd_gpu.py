@@ -135,6 +135,18 @@ def test_training_step_matches_oracle(archi, cuda):
     assert abs(model.last_step_info["data_loss"] - ref["data_loss"]) <= 1e-3 * abs(ref["data_loss"])
     assert abs(loss - ref["loss"]) <= 1e-3 * abs(ref["loss"])
     check_gradients_and_update(grads, ref, ref32, w0, w1, reg=set(ref["net"].reg_kernels), l2=0.0005)
+    # BatchNormalization state after the step only depends on the forward pass: batch mean within 1e-4 of the layer's
+    # std, batch variance within 1e-3 (recovered from the momentum-0.99 update of both sides)
+    for k, v in ref["new_weights"].items():
+        if k.endswith("moving_mean"):
+            kv = k.replace("moving_mean", "moving_variance")
+            old_m, old_v = torch.from_numpy(w0[k]).double(), torch.from_numpy(w0[kv]).double()
+            bm_ref, bm_gpu = (v - 0.99 * old_m) / 0.01, (torch.from_numpy(w1[k]).double() - 0.99 * old_m) / 0.01
+            bv_ref = (ref["new_weights"][kv] - 0.99 * old_v) / 0.01
+            bv_gpu = (torch.from_numpy(w1[kv]).double() - 0.99 * old_v) / 0.01
+            std = float(bv_ref.clamp(min=0).max()) ** 0.5
+            assert float((bm_gpu - bm_ref).abs().max()) <= 1e-4 * std + 1e-6, k
+            assert float((bv_gpu - bv_ref).abs().max()) <= 1e-3 * std * std + 1e-6, kv
 
 
 def test_inference_mode_uses_moving_statistics(cuda):
