@@ -138,6 +138,7 @@ class Plan(object):
         self.grads_cleared = False   # True: the first backward launch zeroes the model's whole flat gradient buffer
         # weight-gradient GEMMs only feed the optimizer, so they run on a second HIP stream and fill the CUs the
         # data-gradient chain leaves idle at its tile-quantisation tails (DJ_SIDE_WGRAD=0 keeps one stream)
+        self.targets_event = None    # set while the side stream encodes y_true (Model._upload), cleared by the loss
         self.side_stream = None
         self.side_enabled = True     # cleared while kernels are timed one by one (bench.py)
         self._side_dirty = False
