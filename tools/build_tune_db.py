@@ -19,6 +19,8 @@ for archi in ("deconv", "ssd_custom", "up_sampling"):
 from jpeg_detection_resnet_ssd_amd.vgg_jpeg_keras.networks.resnet_dct import ResNet50Custom, ResNet50RGB
 from jpeg_detection_resnet_ssd_amd.keras.optimizers import SGD
 for name, build, b in (("deconv classifier", lambda: ResNet50Custom(weights=None, archi="deconv"), 64),
+                       ("late_concat_rfa_thinner classifier", lambda: ResNet50Custom(weights=None, archi="late_concat_rfa_thinner"), 64),
+                       ("resnet_rgb classifier", lambda: ResNet50RGB(weights=None), 64),
                        ("resnet_rgb classifier", lambda: ResNet50RGB(weights=None), 4)):
     K.clear_session()
     m = build()
