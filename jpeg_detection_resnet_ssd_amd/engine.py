@@ -176,11 +176,7 @@ class Plan(object):
     def _on_side(self, fn):
         side, ready = self.side_stream, torch.cuda.Event()
 
-        skip = os.environ.get("DJ_DEBUG_SKIP_WGRAD", "0") == "1"   # timing experiments only: wrong gradients
-
         def run():
-            if skip:
-                return None
             if not self.side_enabled:
                 return fn()
             ready.record()                      # everything issued so far on the main stream (dy, the memset)
