@@ -111,8 +111,8 @@ def cpu_baseline(archi, batch, budget_s=25.0):
 def main(json_out=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--archi", default="deconv", choices=["deconv", "ssd_custom", "up_sampling"])
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (the reference trainer's batch_size)")
     ap.add_argument("--floatx", default="float32", choices=["float32", "float16", "bfloat16"],
