@@ -129,7 +129,10 @@ int dj_bn_bwd_finalize(const float* partial, int nrows, long count, const float*
                        void* stream);
 int dj_bn_bwd_apply(const float* dy, int ld_dy, const float* z, int ld_z, const float* y, int ld_y,
                     const float* scale, const float* shift, int mask_mode, const float* k0, const float* k1,
-                    const float* k2, float* dz, int ld_dz, long rows, int C, void* stream);
+                    const float* k2, float* dz, int ld_dz, long rows, int C, float* dmasked, int ld_dm, int dm_beta,
+                    void* stream);
+/* ... optional second output of dj_bn_bwd_apply: dmasked[r][c] (+)= dy_m, the ReLU-masked upstream gradient itself --
+ * after Add()+Activation('relu') that is the identity shortcut's gradient, written in the same pass (no dj_relu_bwd). */
 /* dx (+)= dy * [y > 0]  (Activation('relu') gradient; `activation="relu"` convs of the SSD head). */
 int dj_relu_bwd(const float* dy, int ld_dy, const float* y, int ld_y, float* dx, int ld_dx, long rows, int C,
                 int beta, void* stream);

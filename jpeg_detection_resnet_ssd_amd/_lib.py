@@ -70,7 +70,7 @@ SIGNATURES = {
     "dj_bn_bwd_reduce": (c_int, [FP, c_int, FP, c_int, FP, c_int, FP, FP, FP, FP, c_int, c_long, c_int, FP, c_void_p]),
     "dj_bn_bwd_finalize": (c_int, [FP, c_int, c_long, FP, FP, FP, FP, FP, FP, FP, FP, c_int, c_void_p]),
     "dj_bn_bwd_apply": (c_int, [FP, c_int, FP, c_int, FP, c_int, FP, FP, c_int, FP, FP, FP, FP, c_int, c_long, c_int,
-                                c_void_p]),
+                                FP, c_int, c_int, c_void_p]),
     "dj_relu_bwd": (c_int, [FP, c_int, FP, c_int, FP, c_int, c_long, c_int, c_int, c_void_p]),
     "dj_copy2d": (c_int, [FP, c_long, FP, c_long, c_long, c_long, c_int, c_void_p]),
     "dj_upsample2x": (c_int, [FP, c_int, FP, c_int, c_int, c_int, c_int, c_int, c_void_p]),

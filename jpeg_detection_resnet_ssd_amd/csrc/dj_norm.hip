@@ -423,7 +423,8 @@ __global__ __launch_bounds__(256) void dj_bn_bwd_apply_kernel(const float* dy, i
                                                                const float* y, int ld_y, const float* scale,
                                                                const float* shift, int mask_mode, const float* k0,
                                                                const float* k1, const float* k2, float* dz, int ld_dz,
-                                                               long rows, int C) {
+                                                               long rows, int C, float* dmasked, int ld_dm,
+                                                               int dm_beta) {
   using IO = VecIO<VEC>;
   const int cv = C / VEC;
   long total = rows * cv;
@@ -443,26 +444,32 @@ __global__ __launch_bounds__(256) void dj_bn_bwd_apply_kernel(const float* dy, i
     g.z = (m.z > 0.f) ? g.z : 0.f;
     g.w = (m.w > 0.f) ? g.w : 0.f;
     IO::st(dz + r * ld_dz + c, IO::ld(k0 + c) * g + IO::ld(k1 + c) * zz + IO::ld(k2 + c));
+    if (dmasked) {   // the masked upstream gradient is also the identity shortcut's gradient (Add + ReLU backward)
+      float* d = dmasked + r * ld_dm + c;
+      IO::st(d, dm_beta ? g + IO::ld(d) : g);
+    }
   }
 }
 
 extern "C" int dj_bn_bwd_apply(const float* dy, int ld_dy, const float* z, int ld_z, const float* y, int ld_y,
                                const float* scale, const float* shift, int mask_mode, const float* k0,
                                const float* k1, const float* k2, float* dz, int ld_dz, long rows, int C,
-                               void* stream) {
+                               float* dmasked, int ld_dm, int dm_beta, void* stream) {
   DJ_CHECK_ARG(dy && z && k0 && k1 && k2 && dz && rows > 0 && C > 0, "bn_bwd_apply: bad arguments");
+  DJ_CHECK_ARG(!dmasked || ld_dm >= C, "bn_bwd_apply: ld_dm < C");
   DJ_CHECK_ARG(mask_mode >= 0 && mask_mode <= 2, "bn_bwd_apply: mask_mode");
   DJ_CHECK_ARG(mask_mode != 1 || y, "bn_bwd_apply: mask_mode 1 needs y");
   DJ_CHECK_ARG(mask_mode != 2 || (scale && shift), "bn_bwd_apply: mask_mode 2 needs scale/shift");
   hipStream_t s = (hipStream_t)stream;
   bool v4 = (C % 4 == 0) && (ld_dy % 4 == 0) && (ld_z % 4 == 0) && (ld_dz % 4 == 0) && (mask_mode != 1 || ld_y % 4 == 0) &&
-            al16(dy) && al16(z) && al16(dz) && al16(y) && al16(scale) && al16(shift) && al16(k0) && al16(k1) && al16(k2);
+            al16(dy) && al16(z) && al16(dz) && al16(y) && al16(scale) && al16(shift) && al16(k0) && al16(k1) && al16(k2) &&
+            al16(dmasked) && (!dmasked || ld_dm % 4 == 0);
   if (v4)
     hipLaunchKernelGGL(dj_bn_bwd_apply_kernel<4>, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, s, dy, ld_dy, z, ld_z,
-                       y, ld_y, scale, shift, mask_mode, k0, k1, k2, dz, ld_dz, rows, C);
+                       y, ld_y, scale, shift, mask_mode, k0, k1, k2, dz, ld_dz, rows, C, dmasked, ld_dm, dm_beta);
   else
     hipLaunchKernelGGL(dj_bn_bwd_apply_kernel<1>, dim3(ew_blocks(rows * C)), dim3(256), 0, s, dy, ld_dy, z, ld_z, y,
-                       ld_y, scale, shift, mask_mode, k0, k1, k2, dz, ld_dz, rows, C);
+                       ld_y, scale, shift, mask_mode, k0, k1, k2, dz, ld_dz, rows, C, dmasked, ld_dm, dm_beta);
   DJ_CHECK_LAUNCH("dj_bn_bwd_apply");
   return DJ_OK;
 }

@@ -88,9 +88,12 @@ class GradRef(object):
     """Gradient of a Value: a buffer, optionally to be masked by `mask_y > 0` by whoever reads it
     (lets Add+ReLU hand its upstream gradient to both branches without materialising the mask)."""
 
-    def __init__(self, buf, mask_y=None):
+    def __init__(self, buf, mask_y=None, also=None):
         self.buf = buf
         self.mask_y = mask_y
+        # (buffer, beta): whoever applies the mask must also store (beta 0) / accumulate (beta 1) the masked gradient
+        # there -- the identity shortcut of a residual block shares it with the BatchNormalization branch
+        self.also = also
 
 
 class Value(object):

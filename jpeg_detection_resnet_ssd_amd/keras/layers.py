@@ -500,6 +500,7 @@ class BatchNormalization(Layer):
         mm, mv = self.moving_mean.param, self.moving_variance.param
         out = Value(z, scale=scale, shift=shift, relu=False, needs_grad=True, name=self.name)
         out.bn = self
+        out.bn_applies_mask = bool(plan.training)   # its backward consumes GradRef.mask_y / .also (see Add)
         if not plan.training:
             plan.emit(lambda: call("dj_bn_infer_coeffs", gamma, beta, mm, mv, self.epsilon, scale, shift, c))
             return out
@@ -540,13 +541,20 @@ class BatchNormalization(Layer):
                                        k1, k2, c))
             plan.note_grad(self.gamma)
             plan.note_grad(self.beta)
+            also = src.grad.also
             if x.needs_grad:
                 dz, beta_acc = plan.grad_of(x)
                 if beta_acc:
                     raise NotImplementedError("BatchNormalization input with several gradient writers")
                 ld_dz = rows_of(dz)[2]
+                dm, dm_beta = also if also is not None else (None, 0)
+                ld_dm = rows_of(dm)[2] if dm is not None else 0
                 plan.emit_bwd(lambda: call("dj_bn_bwd_apply", dy, ld_dy, z, ld, mask_y, ld_y, scale, shift, mode, k0,
-                                           k1, k2, dz, ld_dz, rows, c))
+                                           k1, k2, dz, ld_dz, rows, c, dm, ld_dm, int(dm_beta)))
+            elif also is not None:   # nothing to apply here: the shortcut still needs its masked gradient
+                dm, dm_beta = also
+                plan.emit_bwd(lambda: call("dj_relu_bwd", dy, ld_dy, mask_y, ld_y, dm, rows_of(dm)[2], rows, c,
+                                           int(dm_beta)))
 
         plan.on_backward(build_backward)
         return out
@@ -621,11 +629,18 @@ class Add(Layer):
                 return
             assert out.grad.mask_y is None
             dy = out.grad.buf
+            # identity block: the BatchNormalization branch applies the ReLU mask anyway (dj_bn_bwd_apply); it writes the
+            # masked gradient for the identity shortcut in the same pass instead of a separate dj_relu_bwd sweep
+            fuse = (relu and a.is_affine and a.needs_grad and not b.is_affine and b.needs_grad
+                    and getattr(a, "bn_applies_mask", False))
             for v in (a, b):
                 if not v.needs_grad:
                     continue
                 if v.is_affine:
-                    plan.set_grad_ref(v, GradRef(dy, y if relu else None))
+                    also = plan.grad_of(b) if (fuse and v is a) else None
+                    plan.set_grad_ref(v, GradRef(dy, y if relu else None, also=also))
+                elif fuse:
+                    continue
                 else:
                     dv, beta = plan.grad_of(v)
                     if relu:

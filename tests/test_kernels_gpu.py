@@ -54,7 +54,7 @@ def test_batchnorm_train_forward_backward(shape, cuda, E):
     dz = torch.empty_like(xd)
     E.call("dj_bn_bwd_reduce", dyd, c, xd, c, None, 0, smean, sinv, scale, shift, 2, rows, c, part)
     E.call("dj_bn_bwd_finalize", part, nr, rows, gd, smean, sinv, dg, db, k0, k1, k2, c)
-    E.call("dj_bn_bwd_apply", dyd, c, xd, c, None, 0, scale, shift, 2, k0, k1, k2, dz, c, rows, c)
+    E.call("dj_bn_bwd_apply", dyd, c, xd, c, None, 0, scale, shift, 2, k0, k1, k2, dz, c, rows, c, None, 0, 0)
     torch.cuda.synchronize()
     assert close(dg, gr.grad) and close(db, br.grad)
     assert close(dz, xr.grad, rel=2e-3)
@@ -62,9 +62,12 @@ def test_batchnorm_train_forward_backward(shape, cuda, E):
     dz1 = torch.empty_like(xd)
     E.call("dj_bn_bwd_reduce", dyd, c, xd, c, y, c, smean, sinv, None, None, 1, rows, c, part)
     E.call("dj_bn_bwd_finalize", part, nr, rows, gd, smean, sinv, dg, db, k0, k1, k2, c)
-    E.call("dj_bn_bwd_apply", dyd, c, xd, c, y, c, None, None, 1, k0, k1, k2, dz1, c, rows, c)
+    dm = torch.full((rows, c), 2.0, device=cuda)
+    E.call("dj_bn_bwd_apply", dyd, c, xd, c, y, c, None, None, 1, k0, k1, k2, dz1, c, rows, c, dm, c, 1)
     torch.cuda.synchronize()
     assert close(dz1, xr.grad, rel=2e-3)
+    # ... and the second output accumulated the ReLU-masked upstream gradient (the identity shortcut's gradient)
+    assert torch.equal(dm.cpu(), (2.0 + dyd * (y > 0)).reshape(rows, c).cpu())
 
 
 def test_add_relu_and_relu_bwd_and_copy(cuda, E):
