@@ -675,6 +675,7 @@ class Concatenate(Layer):
 
     def lower(self, plan, model, ins):
         bufs = [_materialised(v, self.name, plan) for v in ins]
+        v_of = {id(t): v for t, v in zip(bufs, ins)}
         nd = bufs[0].dim()
         ax = self.axis % nd
         assert ax >= 1
@@ -699,8 +700,13 @@ class Concatenate(Layer):
                 assert t.is_contiguous()
                 src, lds, rws = t, n, outer
             dst = yflat[:, off:off + n]
-            plan.emit(lambda src=src, lds=lds, dst=dst, rws=rws, n=n: call("dj_copy2d", src, lds, dst, total, rws, n, 0))
+            copy = (lambda src=src, lds=lds, dst=dst, rws=rws, n=n: call("dj_copy2d", src, lds, dst, total, rws, n, 0))
+            if getattr(v_of[id(t)], "constant", False):
+                copy()              # constant input (the anchor boxes): its slice of y is written once, now
+            else:
+                plan.emit(copy)
         out = Value(y, needs_grad=any(v.needs_grad for v in ins), name=self.name)
+        out.constant = all(getattr(v, "constant", False) for v in ins)
 
         def build_backward():
             if out.grad is None:
@@ -752,6 +758,7 @@ class Reshape(Layer):
         out = Value(xbuf.view(*shape), needs_grad=x.needs_grad, name=self.name)
         out.alias_of = x
         out.alias_view = lambda g: g.view(*shape)
+        out.constant = getattr(x, "constant", False)
         return out
 
 

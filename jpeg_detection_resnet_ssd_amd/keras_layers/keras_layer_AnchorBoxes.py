@@ -72,4 +72,6 @@ class AnchorBoxes(Layer):
         a = torch.from_numpy(self.anchors().astype(np.float32))
         buf = plan.empty(plan.batch_size, *a.shape)
         buf.copy_(a.unsqueeze(0).expand(plan.batch_size, *a.shape))
-        return Value(buf, needs_grad=False, name=self.name)
+        out = Value(buf, needs_grad=False, name=self.name)
+        out.constant = True   # filled here once: Reshape / Concatenate downstream copy it at plan build, not per step
+        return out
