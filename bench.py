@@ -48,7 +48,7 @@ def measure_conv_kernels(model, plan):
             return r
         setattr(Kn, name, timed)
 
-    for n in ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad"):
+    for n in ("conv2d_fwd", "conv2d_fwd_addrelu", "conv2d_dgrad", "conv2d_wgrad"):
         wrap(n)
     try:
         plan.side_enabled = False      # one stream: a launch's events bracket that launch alone

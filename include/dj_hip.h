@@ -64,6 +64,19 @@ int dj_conv2d_nhwc_fwd(const dj_conv2d_desc* d, const float* x, const float* w, 
 int dj_conv2d_nhwc_dgrad(const dj_conv2d_desc* d, const float* dy, const float* w, const float* bias,
                          float* dx, int beta, void* stream);
 
+/* Residual Add + ReLU evaluated inside the consumer (the first 1x1 conv of the next bottleneck block,
+ * L/models/keras_ssd300_dct_j2d_resnet.py:96-99 then :66-68): the conv's input is
+ *   a[m][c] = relu(x[m][c]*pro_scale[c] + pro_shift[c] + res[m][c]*res_scale[c] + res_shift[c])
+ * (res_scale/res_shift NULL: res taken as is -- an identity shortcut), computed while the A tile is staged; when
+ * sum_out != NULL the tensor `a` -- the output of Add()+Activation('relu') that later layers and the backward pass
+ * read -- is stored there by the same launch.  Only for 1x1, stride-1, unpadded convs with in_c % 32 == 0
+ * (dj_conv2d_fwd_addrelu_supported() != 0); any other geometry is an error, never a silent slow path. */
+int dj_conv2d_fwd_addrelu_supported(const dj_conv2d_desc* d);
+int dj_conv2d_nhwc_fwd_addrelu(const dj_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y,
+                               const float* pro_scale, const float* pro_shift, const float* res, int ld_res,
+                               const float* res_scale, const float* res_shift, float* sum_out, int ld_sum, int relu,
+                               float* stats, void* stream);
+
 /* Debug/test switch: 0 forces the generic (branchy, any-shape) implicit-GEMM kernel, 1 (default) lets the
  * launcher pick the branch-free buffer-load kernel whenever its alignment preconditions hold. */
 void dj_set_fast_path(int enable);

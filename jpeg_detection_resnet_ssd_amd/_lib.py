@@ -53,6 +53,9 @@ SIGNATURES = {
     "dj_conv2d_nhwc_fwd": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, FP, c_int, c_int, FP, c_void_p]),
     "dj_conv2d_nhwc_dgrad": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, c_int, c_void_p]),
     "dj_conv2d_nhwc_wgrad": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, c_int, c_int, c_void_p]),
+    "dj_conv2d_fwd_addrelu_supported": (c_int, [POINTER(ConvDesc)]),
+    "dj_conv2d_nhwc_fwd_addrelu": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, FP, FP, c_int, FP, FP, FP, c_int, c_int, FP,
+                                           c_void_p]),
     "dj_set_fast_path": (None, [c_int]),
     "dj_set_compute_mode": (c_int, [c_int]),
     "dj_get_compute_mode": (c_int, []),

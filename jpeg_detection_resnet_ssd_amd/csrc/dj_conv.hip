@@ -172,9 +172,18 @@ extern "C" int dj_conv2d_fwd_stats_rows(const dj_conv2d_desc* d) {
   return dj_cdiv((long)d->batch * d->out_h * d->out_w, 64);
 }
 
-extern "C" int dj_conv2d_nhwc_fwd(const dj_conv2d_desc* d, const float* x, const float* w, const float* bias,
-                                  float* y, const float* pro_scale, const float* pro_shift, int pro_relu, int relu,
-                                  float* stats, void* stream) {
+struct FwdResidual {
+  const float* res = nullptr;
+  int ld_res = 0;
+  const float* res_scale = nullptr;
+  const float* res_shift = nullptr;
+  float* sum_out = nullptr;
+  int ld_sum = 0;
+};
+
+static int conv_fwd_impl(const dj_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y,
+                         const float* pro_scale, const float* pro_shift, int pro_relu, int relu, float* stats,
+                         const FwdResidual& rz, void* stream) {
   if (int rc = check_desc(d)) return rc;
   DJ_CHECK_ARG(x && w && y, "conv fwd: null tensor");
   DJ_CHECK_ARG((pro_scale == nullptr) == (pro_shift == nullptr), "conv fwd: pro_scale/pro_shift must come together");
@@ -207,6 +216,16 @@ extern "C" int dj_conv2d_nhwc_fwd(const dj_conv2d_desc* d, const float* x, const
            (!pro_scale || (aligned16(pro_scale) && aligned16(pro_shift)));
   p.vecB = (d->out_c % 4 == 0) && aligned16(w);
   p.a_bytes = extent_bytes((long)d->batch * d->in_h * d->in_w, d->ld_x, d->in_c);
+  if (rz.res) {
+    p.A2 = rz.res;
+    p.ldsrc2 = rz.ld_res;
+    p.pro_scale2 = rz.res_scale;
+    p.pro_shift2 = rz.res_shift;
+    p.sum_out = rz.sum_out;
+    p.ld_sum = rz.ld_sum;
+    p.a2_bytes = extent_bytes((long)d->batch * d->in_h * d->in_w, rz.ld_res, d->in_c);
+    p.sum_bytes = rz.sum_out ? extent_bytes((long)d->batch * d->in_h * d->in_w, rz.ld_sum, d->in_c) : 0;
+  }
   p.b_bytes = extent_bytes((long)p.K, d->out_c, d->out_c);
   int splits = 1;
   int cfg = choose_cfg(p.M, p.N, p.K, stats == nullptr, &splits);
@@ -223,6 +242,10 @@ extern "C" int dj_conv2d_nhwc_fwd(const dj_conv2d_desc* d, const float* x, const
       return DJ_ERR_HIP;
     }
   }
+  if (rz.res) {
+    DJ_CHECK_ARG(dj_fast_mode_fwd(p) == 3, "conv fwd (residual add): the branch-free kernel's preconditions do not hold "
+                                           "(channels %% 32, 16-byte aligned tensors)");
+  }
   if (int rc = dj_launch_cfg<0, 0>(cfg, p, splits, s)) return rc;
   if (splits > 1 && relu) {
     long total = (long)p.M * p.N;
@@ -231,6 +254,43 @@ extern "C" int dj_conv2d_nhwc_fwd(const dj_conv2d_desc* d, const float* x, const
     DJ_CHECK_LAUNCH("dj_relu_rows_kernel");
   }
   return DJ_OK;
+}
+
+extern "C" int dj_conv2d_nhwc_fwd(const dj_conv2d_desc* d, const float* x, const float* w, const float* bias,
+                                  float* y, const float* pro_scale, const float* pro_shift, int pro_relu, int relu,
+                                  float* stats, void* stream) {
+  return conv_fwd_impl(d, x, w, bias, y, pro_scale, pro_shift, pro_relu, relu, stats, FwdResidual(), stream);
+}
+
+// 1x1 stride-1 convolution whose input is relu(x*pro_scale+pro_shift + res*res_scale+res_shift): the residual Add + ReLU
+// of a bottleneck block evaluated while the A tile is staged; `sum_out` (optional) receives that input tensor.
+extern "C" int dj_conv2d_fwd_addrelu_supported(const dj_conv2d_desc* d) {
+  if (check_desc(d)) return 0;
+  return d->kernel_h == 1 && d->kernel_w == 1 && d->stride_h == 1 && d->stride_w == 1 && d->pad_top == 0 &&
+         d->pad_left == 0 && d->in_h == d->out_h && d->in_w == d->out_w && d->in_c % 32 == 0 && d->ld_x % 4 == 0 &&
+         d->out_c % 4 == 0;
+}
+
+extern "C" int dj_conv2d_nhwc_fwd_addrelu(const dj_conv2d_desc* d, const float* x, const float* w, const float* bias,
+                                          float* y, const float* pro_scale, const float* pro_shift, const float* res,
+                                          int ld_res, const float* res_scale, const float* res_shift, float* sum_out,
+                                          int ld_sum, int relu, float* stats, void* stream) {
+  DJ_CHECK_ARG(d && dj_conv2d_fwd_addrelu_supported(d), "conv fwd (residual add): needs a 1x1 stride-1 unpadded conv with "
+                                                         "in_c %% 32 == 0");
+  DJ_CHECK_ARG(res && pro_scale && pro_shift, "conv fwd (residual add): res, pro_scale and pro_shift are required");
+  DJ_CHECK_ARG((res_scale == nullptr) == (res_shift == nullptr), "conv fwd (residual add): res_scale/res_shift come together");
+  DJ_CHECK_ARG(ld_res >= d->in_c && ld_res % 4 == 0 && (!sum_out || (ld_sum >= d->in_c && ld_sum % 4 == 0)),
+               "conv fwd (residual add): bad ld_res / ld_sum");
+  DJ_CHECK_ARG(aligned16(res) && aligned16(sum_out) && aligned16(res_scale) && aligned16(res_shift),
+               "conv fwd (residual add): tensors must be 16-byte aligned");
+  FwdResidual rz;
+  rz.res = res;
+  rz.ld_res = ld_res;
+  rz.res_scale = res_scale;
+  rz.res_shift = res_shift;
+  rz.sum_out = sum_out;
+  rz.ld_sum = ld_sum;
+  return conv_fwd_impl(d, x, w, bias, y, pro_scale, pro_shift, 1, relu, stats, rz, stream);
 }
 
 extern "C" int dj_conv2d_nhwc_dgrad(const dj_conv2d_desc* d, const float* dy, const float* w, const float* bias,

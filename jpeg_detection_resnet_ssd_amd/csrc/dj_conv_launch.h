@@ -62,6 +62,16 @@ static int launch_one(const DjIgemmParams& p, int splits, hipStream_t s, int fas
   if (fast == 2)
     return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 1, NSTAGE>, smem_fast, BM, BN, p, splits, s,
                          &done[2]);
+  if (fast == 3) {   // residual-add prologue: forward GEMM only
+    if constexpr (AM == 0 && BMD == 0) {
+      static bool done3 = false;
+      return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 3, NSTAGE>, smem_fast, BM, BN, p, splits, s,
+                           &done3);
+    } else {
+      dj_set_error("residual-add prologue outside the forward GEMM");
+      return DJ_ERR_ARG;
+    }
+  }
   return launch_kernel(dj_igemm_kernel<BM, BN, WM, WN, AM, BMD>, Cfg::SMEM_BYTES, BM, BN, p, splits, s, &done[0]);
 }
 
@@ -73,6 +83,16 @@ static int launch_k2(const DjIgemmParams& p, int splits, hipStream_t s, int fast
   if (fast == 1)
     return launch_kernel(dj_igemm_fast_kernel<BM, BN, 2, 2, AM, BMD, 0, 4, 0, 2>, 2 * Cfg::SMEM_BYTES, BM, BN, p, splits, s,
                          &done[0], 512);
+  if (fast == 3) {
+    if constexpr (AM == 0 && BMD == 0) {
+      static bool done3 = false;
+      return launch_kernel(dj_igemm_fast_kernel<BM, BN, 2, 2, AM, BMD, 3, 4, 0, 2>, 2 * Cfg::SMEM_BYTES, BM, BN, p, splits,
+                           s, &done3, 512);
+    } else {
+      dj_set_error("residual-add prologue outside the forward GEMM");
+      return DJ_ERR_ARG;
+    }
+  }
   return launch_kernel(dj_igemm_fast_kernel<BM, BN, 2, 2, AM, BMD, 1, 4, 0, 2>, 2 * Cfg::SMEM_BYTES, BM, BN, p, splits, s,
                        &done[1], 512);
 }
@@ -93,10 +113,13 @@ static int fast_mode(const DjIgemmParams& p) {
   if (AM == 2 && (p.srcC % 4 != 0 || p.K >= (1 << 24))) return 0;
   if (BMD == 0 && (p.N % 4 != 0 || p.ldb % 4 != 0)) return 0;
   if (BMD == 1 && p.srcC % 32 != 0) return 0;
+  if (p.A2) return (AM == 0 && BMD == 0 && p.pro_scale) ? 3 : 0;
   return p.pro_scale ? 2 : 1;
 }
 
 // reduced-precision MFMA variants exist for the two-stage 128x128 / 128x64 / 64x64 tiles of the fast kernel
+static inline int dj_fast_mode_fwd(const DjIgemmParams& p) { return fast_mode<0, 0>(p); }
+
 template <int BM, int BN, int AM, int BMD, int PREC>
 static int launch_lowp(const DjIgemmParams& p, int splits, hipStream_t s, int fast) {
   using Cfg = DjIgemmCfg<BM, BN, 2, 2, AM, BMD>;
@@ -104,6 +127,16 @@ static int launch_lowp(const DjIgemmParams& p, int splits, hipStream_t s, int fa
   if (fast == 1)
     return launch_kernel(dj_igemm_fast_kernel<BM, BN, 2, 2, AM, BMD, 0, 2, PREC>, Cfg::SMEM_BYTES, BM, BN, p, splits, s,
                          &done[0]);
+  if (fast == 3) {
+    if constexpr (AM == 0 && BMD == 0) {
+      static bool done3 = false;
+      return launch_kernel(dj_igemm_fast_kernel<BM, BN, 2, 2, AM, BMD, 3, 2, PREC>, Cfg::SMEM_BYTES, BM, BN, p, splits, s,
+                           &done3);
+    } else {
+      dj_set_error("residual-add prologue outside the forward GEMM");
+      return DJ_ERR_ARG;
+    }
+  }
   return launch_kernel(dj_igemm_fast_kernel<BM, BN, 2, 2, AM, BMD, 1, 2, PREC>, Cfg::SMEM_BYTES, BM, BN, p, splits, s,
                        &done[1]);
 }

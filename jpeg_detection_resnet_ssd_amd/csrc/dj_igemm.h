@@ -50,6 +50,13 @@ struct DjIgemmParams {
   int vecA, vecB;          // 16-byte loads legal for A / B
   float inv_rowHW, inv_rowW;  // 1/(rowH*rowW), 1/rowW for the pixel decomposition of the fast wgrad path
   int a_bytes, b_bytes;       // byte extents of A and B for the buffer descriptors of the fast path
+  // residual-add prologue of the fast forward kernel (1x1, stride 1): A = relu(A*scale+shift + A2*scale2+shift2),
+  // optionally stored to sum_out by the workgroups of column tile 0 (this conv then IS the Add + ReLU pass)
+  const float* A2;
+  const float* pro_scale2;  // null: A2 is taken as is
+  const float* pro_shift2;
+  float* sum_out;
+  int ldsrc2, ld_sum, a2_bytes, sum_bytes;
 };
 
 template <int BM, int BN, int WM, int WN, int AM, int BMD>

@@ -40,7 +40,10 @@ __device__ __forceinline__ dj_short4 dj_to_bf16x4(f32x4 v) {
                    __builtin_bit_cast(short, d)};
 }
 
-// PRO: 0 = plain A, 1 = A*scale[c]+shift[c] (then max(., floor) with floor = 0 or -inf) on in-bounds elements
+// PRO: 0 = plain A, 1 = A*scale[c]+shift[c] (then max(., floor) with floor = 0 or -inf) on in-bounds elements,
+//      3 = residual add: relu(A*scale+shift + A2*scale2+shift2) with a second gathered tensor A2 (1x1 stride-1 forward
+//          only); the workgroups of column tile 0 also store that sum -- the Add()+Activation('relu') output -- to
+//          p.sum_out, so the separate elementwise pass (read, read, write, then read again by this conv) disappears
 // PREC: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1 = operands rounded to fp16, 2 = to bf16 when the fragments
 //       are read, one v_mfma_f32_32x32x8_{f16,bf16} per 8-deep k group (same lane <-> k mapping as the four fp32
 //       MFMAs it replaces), fp32 accumulation.  HBM and LDS contents stay fp32 ("fp32 master" tensors).
@@ -91,7 +94,12 @@ __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmPa
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)p.pro_scale, 0, PRO ? p.srcC * 4 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void*)p.pro_shift, 0, PRO ? p.srcC * 4 : 0, 0x00020000);
-  const float relu_floor = p.pro_relu ? 0.f : -INFINITY;
+  const float relu_floor = (p.pro_relu || PRO == 3) ? 0.f : -INFINITY;
+  const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A2, 0, PRO == 3 ? p.a2_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rS2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.pro_scale2, 0, (PRO == 3 && p.pro_scale2) ? p.srcC * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rT2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.pro_shift2, 0, (PRO == 3 && p.pro_scale2) ? p.srcC * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)p.sum_out, 0, (PRO == 3 && p.sum_out) ? p.sum_bytes : 0, 0x00020000);
+  const bool store_sum = (PRO == 3) && p.sum_out != nullptr && tile_n == 0;
 
   // ---------------- per-thread staging state ----------------
   const int ac = tid & 7, ar0 = tid >> 3;              // A k-contiguous: (row ar0+32j, chunk ac)
@@ -100,6 +108,7 @@ __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmPa
   const int bc = tid & 7, br0 = tid >> 3;                  // B k-contiguous
 
   int a_off[NA], a_rh[NA], a_rw[NA];   // modes 0/1: byte offset of (row, tap 0, c 0) + chunk; row coordinates
+  int a2_off[PRO == 3 ? NA : 1], y_off[PRO == 3 ? NA : 1];   // PRO 3: same pixel in A2 / sum_out
   // mode 2: thread -> (pixel row ar0 of the K-step, m' chunks ac + 8 i): ONE pixel decomposition per K-step
   int a2_c[NA], a2_dh[NA], a2_dw[NA];
   bool a2_ok[NA];
@@ -118,10 +127,18 @@ __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmPa
         a_rh[j] = rh;
         a_rw[j] = rw;
         a_off[j] = ((img * p.srcH * p.srcW + rh * p.srcW + rw) * p.ldsrc + 4 * ac) * 4;
+        if (PRO == 3) {
+          a2_off[j] = (m * p.ldsrc2 + 4 * ac) * 4;
+          y_off[j] = (m * p.ld_sum + 4 * ac) * 4;
+        }
       } else {
         a_rh[j] = -(1 << 28);
         a_rw[j] = -(1 << 28);
         a_off[j] = 0;
+        if (PRO == 3) {
+          a2_off[j] = 0;
+          y_off[j] = 0;
+        }
       }
     }
   } else {
@@ -173,6 +190,8 @@ __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmPa
     f32x4 ra[NA], rb[NB];
     unsigned a_valid;  // bit j: row j of the prefetched A tile is in bounds (needed when PRO)
     f32x4 psc, psh;
+    f32x4 ra2[PRO == 3 ? NA : 1], psc2, psh2;   // PRO 3: the residual operand and its affine
+    int c0;                                       // PRO 3: first channel of this K-step (for the sum_out store)
   };
   Regs r0, r1;
   r0.a_valid = r1.a_valid = 0;
@@ -193,6 +212,15 @@ __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmPa
         psc = dj_buf_ld4(rS, (unsigned)(t_c0 + 4 * ac) * 4u);
         psh = dj_buf_ld4(rT, (unsigned)(t_c0 + 4 * ac) * 4u);
       }
+      if (PRO == 3) {
+        R.c0 = t_c0;
+        R.psc2 = f32x4{1.f, 1.f, 1.f, 1.f};
+        R.psh2 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.pro_scale2) {
+          R.psc2 = dj_buf_ld4(rS2, (unsigned)(t_c0 + 4 * ac) * 4u);
+          R.psh2 = dj_buf_ld4(rT2, (unsigned)(t_c0 + 4 * ac) * 4u);
+        }
+      }
       a_valid = 0;
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
@@ -200,6 +228,7 @@ __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmPa
         int w = (AM == 0) ? a_rw[j] + dw : a_rw[j] - dw;
         bool ok = live && (unsigned)h < (unsigned)p.srcH && (unsigned)w < (unsigned)p.srcW;
         ra[j] = dj_buf_ld4(rA, ok ? (unsigned)(a_off[j] + delta) : DJ_OOB);
+        if (PRO == 3) R.ra2[j] = dj_buf_ld4(rA2, ok ? (unsigned)(a2_off[j] + t_c0 * 4) : DJ_OOB);
         a_valid |= ok ? (1u << j) : 0u;
       }
     } else {
@@ -265,12 +294,16 @@ __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmPa
       for (int j = 0; j < NA; ++j) {
         f32x4 sc = (AM == 2) ? a2_sc[j] : psc, sh = (AM == 2) ? a2_sh[j] : psh;
         f32x4 v = ra[j] * sc + sh;
+        if (PRO == 3) v += R.ra2[j] * R.psc2 + R.psh2;
         bool ok = (a_valid >> j) & 1u;
         v.x = ok ? fmaxf(v.x, relu_floor) : 0.f;
         v.y = ok ? fmaxf(v.y, relu_floor) : 0.f;
         v.z = ok ? fmaxf(v.z, relu_floor) : 0.f;
         v.w = ok ? fmaxf(v.w, relu_floor) : 0.f;
         ra[j] = v;
+        if (PRO == 3 && store_sum)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rY,
+                                                 ok ? (int)(y_off[j] + R.c0 * 4) : (int)DJ_OOB, 0, 0);
       }
     }
   };

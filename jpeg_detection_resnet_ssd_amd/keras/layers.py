@@ -3,6 +3,7 @@
 classification_part/vgg_jpeg_keras/networks/resnet_dct.py), each with a `lower()` that turns it into
 C-ABI launches inside an engine.Plan.  Same constructor keywords, defaults, auto-naming and
 `_keras_shape` / `output_shape` attributes as Keras, so builder code reads like the reference's."""
+import os
 import re
 
 import numpy as np
@@ -275,8 +276,18 @@ class Conv2D(Layer):
             nrows = Kn.conv2d_stats_rows(desc)
             stats = plan.empty(nrows, 2, self.filters)
         xbuf = x.buf
-        plan.emit_conv(4 if stats is not None else 0, desc,
-                       lambda: Kn.conv2d_fwd(desc, xbuf, wgt, bias, y, pro[0], pro[1], pro[2], relu, stats))
+        pend = getattr(x, "pending_add", None)
+        if pend is not None:
+            # x = relu(bn(z) + shortcut) has not been computed yet: this conv evaluates it while staging its A tile and
+            # writes it to xbuf for everybody else (Add.lower picked this layer because it runs first)
+            assert pend["consumer"] is self, "a residual sum must be materialised by its first consumer"
+            zb, zs, zt, rb, rs, rt = pend["z"], pend["z_scale"], pend["z_shift"], pend["res"], pend["res_scale"], pend["res_shift"]
+            plan.emit_conv(4 if stats is not None else 0, desc,
+                           lambda: Kn.conv2d_fwd_addrelu(desc, zb, wgt, bias, y, zs, zt, rb, rs, rt, xbuf, relu, stats))
+            x.pending_add = None
+        else:
+            plan.emit_conv(4 if stats is not None else 0, desc,
+                           lambda: Kn.conv2d_fwd(desc, xbuf, wgt, bias, y, pro[0], pro[1], pro[2], relu, stats))
         out = Value(y, needs_grad=True, name=self.name)
         if stats is not None:
             out.conv_stats = (stats, stats.shape[0], bias)
@@ -605,6 +616,24 @@ class Add(Layer):
     def compute_output_shape(self, input_shape):
         return input_shape[0]
 
+    @staticmethod
+    def _first_consumer_conv(plan, model, relu_layer, a, y):
+        """The layer that runs first among the consumers of relu(Add) if it can take the sum as a fused prologue."""
+        if os.environ.get("DJ_FUSE_ADD", "1") == "0" or relu_layer is None or not a.is_affine:
+            return None
+        if not (a.buf.is_contiguous() and y.dim() == 4):
+            return None
+        users = model.consumers_of(relu_layer.outbound[0])
+        if not users:
+            return None
+        first = min(users, key=model.layers.index)
+        if not (isinstance(first, Conv2D) and not isinstance(first, Conv2DTranspose) and first.kernel_size == (1, 1)
+                and first.strides == (1, 1) and first.dilation_rate == (1, 1)):
+            return None
+        b_, h, w, cin = y.shape
+        desc = Kn.make_conv_desc(b_, h, w, cin, first.filters, (1, 1), (1, 1), "valid", (1, 1))
+        return first if Kn.conv2d_fwd_addrelu_supported(desc) else None
+
     def lower(self, plan, model, ins):
         a, b = ins
         if not a.is_affine and b.is_affine:
@@ -620,9 +649,16 @@ class Add(Layer):
         ldb = rows_of(b.buf)[2]
         y = plan.empty(*a.buf.shape)
         abuf, bbuf = a.buf, b.buf
-        plan.emit(lambda: call("dj_affine_act", abuf, lda, a.scale, a.shift, bbuf, ldb, b.scale, b.shift, y, c, rows,
-                               c, int(relu)))
         out = Value(y, needs_grad=a.needs_grad or b.needs_grad, name=self.name)
+        first = self._first_consumer_conv(plan, model, consumers[0] if relu else None, a, y) if relu else None
+        if first is not None:
+            # no launch here: `first` (the next block's 1x1 conv) computes relu(bn(a) + b) in its A-tile prologue and
+            # stores it to y (dj_conv2d_nhwc_fwd_addrelu) -- one elementwise pass and one read of y less per block
+            out.pending_add = dict(consumer=first, z=abuf, z_scale=a.scale, z_shift=a.shift, res=bbuf, res_scale=b.scale,
+                                   res_shift=b.shift)
+        else:
+            plan.emit(lambda: call("dj_affine_act", abuf, lda, a.scale, a.shift, bbuf, ldb, b.scale, b.shift, y, c, rows,
+                                   c, int(relu)))
 
         def build_backward():
             if out.grad is None:

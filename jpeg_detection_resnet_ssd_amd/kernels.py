@@ -87,6 +87,23 @@ def conv2d_fwd(desc, x, w, bias, y, pro_scale=None, pro_shift=None, pro_relu=Fal
     return y
 
 
+def conv2d_fwd_addrelu_supported(desc):
+    return bool(_lib.load().dj_conv2d_fwd_addrelu_supported(desc))
+
+
+def conv2d_fwd_addrelu(desc, x, w, bias, y, pro_scale, pro_shift, res, res_scale=None, res_shift=None, sum_out=None,
+                       relu=False, stats=None):
+    """1x1 stride-1 conv of relu(x*pro_scale+pro_shift + res*res_scale+res_shift); `sum_out` receives that input."""
+    d = _desc_for(desc, x, y)
+    assert w.is_contiguous() and tuple(w.shape) == (d.kernel_h, d.kernel_w, d.in_c, d.out_c)
+    assert tuple(res.shape) == tuple(x.shape) and (sum_out is None or tuple(sum_out.shape) == tuple(x.shape))
+    check(_lib.load().dj_conv2d_nhwc_fwd_addrelu(d, ptr(x), ptr(w), ptr(bias), ptr(y), ptr(pro_scale), ptr(pro_shift),
+                                                 ptr(res), _pixel_ld(res), ptr(res_scale), ptr(res_shift), ptr(sum_out),
+                                                 _pixel_ld(sum_out) if sum_out is not None else 0, int(relu), ptr(stats),
+                                                 _stream()), "dj_conv2d_nhwc_fwd_addrelu")
+    return y
+
+
 def conv2d_dgrad(desc, dy, w, dx, bias=None, beta=False):
     d = _desc_for(desc, dx, dy)
     assert w.is_contiguous() and tuple(w.shape) == (d.kernel_h, d.kernel_w, d.in_c, d.out_c)

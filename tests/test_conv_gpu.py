@@ -210,3 +210,42 @@ def test_every_tile_variant(case, cuda):
             assert (dw.cpu().double() - wr.grad).abs().max() <= _tol(wr.grad), tag
     for direction in (4, 1, 2):
         _lib.check(lib.dj_conv2d_tune_set(direction, desc, -1, 1), "tune_set")
+
+
+@pytest.mark.parametrize("geom", [(3, 19, 19, 256, 64), (2, 38, 38, 64, 256), (2, 10, 10, 512, 128), (1, 5, 5, 96, 32)])
+@pytest.mark.parametrize("res_affine", [False, True])
+def test_fwd_with_residual_add_prologue(geom, res_affine, cuda):
+    """dj_conv2d_nhwc_fwd_addrelu: conv1x1(relu(bn(z) + shortcut)) in one launch, the sum written as a by-product,
+    BN statistics of the conv output in the epilogue -- every tile variant."""
+    from jpeg_detection_resnet_ssd_amd import _lib
+    from jpeg_detection_resnet_ssd_amd import kernels as K
+    lib = _lib.load()
+    b, h, w, ci, co = geom
+    g = torch.Generator().manual_seed(5)
+    z, r = torch.randn(b, h, w, ci, generator=g), torch.randn(b, h, w, ci, generator=g)
+    wt = torch.randn(1, 1, ci, co, generator=g) * (2.0 / ci) ** 0.5
+    bias = torch.randn(co, generator=g)
+    sc, sh = torch.rand(ci, generator=g) + 0.5, torch.randn(ci, generator=g)
+    rs, rt = (torch.rand(ci, generator=g) + 0.5, torch.randn(ci, generator=g)) if res_affine else (None, None)
+    a = torch.relu(z.double() * sc.double() + sh.double() + (r.double() * rs.double() + rt.double() if res_affine else r.double()))
+    yr = ko.conv2d(a, wt.double(), bias.double(), (1, 1), "valid")
+    y_nobias = (yr - bias.double()).reshape(-1, co)
+    desc = K.make_conv_desc(b, h, w, ci, co, (1, 1), (1, 1), "valid", (1, 1))
+    assert K.conv2d_fwd_addrelu_supported(desc)
+    dev = [t.to(cuda) if t is not None else None for t in (z, r, wt, bias, sc, sh, rs, rt)]
+    zd, rd, wd, bd, scd, shd, rsd, rtd = dev
+    rows = K.conv2d_stats_rows(desc)
+    for cfg in range(lib.dj_conv2d_tune_configs()):
+        _lib.check(lib.dj_conv2d_tune_set(4, desc, cfg, 1), "tune_set")
+        y = torch.empty(b, h, w, co, device=cuda)
+        s_out = torch.full((b, h, w, ci), float("nan"), device=cuda)
+        stats = torch.zeros(rows, 2, co, device=cuda)
+        K.conv2d_fwd_addrelu(desc, zd, wd, bd, y, scd, shd, rd, rsd, rtd, s_out, False, stats)
+        torch.cuda.synchronize()
+        assert (s_out.cpu().double() - a).abs().max() <= 1e-5 * float(a.abs().max()) + 1e-6, cfg
+        assert (y.cpu().double() - yr).abs().max() <= _tol(yr), cfg
+        st = stats.cpu().double()
+        assert (st[:, 0].sum(0) - y_nobias.sum(0)).abs().max() <= 1e-3 * float(y_nobias.sum(0).abs().max()) + 1e-3, cfg
+    _lib.check(lib.dj_conv2d_tune_set(4, desc, -1, 1), "tune_set")
+    bad = K.make_conv_desc(b, h, w, ci, co, (3, 3), (1, 1), "same", (1, 1))
+    assert not K.conv2d_fwd_addrelu_supported(bad)

@@ -21,7 +21,7 @@ def wrap(name):
                      2.0 * desc.batch * desc.out_h * desc.out_w * desc.out_c * desc.kernel_h * desc.kernel_w * desc.in_c))
         return r
     setattr(Kn, name, timed)
-for n in ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad"): wrap(n)
+for n in ("conv2d_fwd", "conv2d_fwd_addrelu", "conv2d_dgrad", "conv2d_wgrad"): wrap(n)
 model.run_train_step(plan); torch.cuda.synchronize()
 agg = collections.OrderedDict()
 for name, key, e0, e1, fl in recs:
