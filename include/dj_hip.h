@@ -152,6 +152,16 @@ int dj_relu_bwd(const float* dy, int ld_dy, const float* y, int ld_y, float* dx,
 /* dst[r][c] (+)= src[r][c]: Concatenate / Reshape+Concatenate(axis=1) and their gradients
  * (L/models/...resnet.py:461,836-879,1713-1714). */
 int dj_copy2d(const float* src, long ld_src, float* dst, long ld_dst, long rows, long cols, int beta, void* stream);
+/* The same for up to DJ_COPY_PARTS (src, dst) pairs in one launch: Concatenate(axis=1) over the six SSD sources and its
+ * gradient (L/models/keras_ssd300_dct_j2d_resnet.py:825-879). */
+#define DJ_COPY_PARTS 8
+typedef struct dj_copy_part {
+  const float* src;
+  float* dst;
+  long ld_src, ld_dst, rows, cols;
+  int beta; /* 1: dst += src */
+} dj_copy_part;
+int dj_copy2d_multi(const dj_copy_part* parts, int n_parts, void* stream);
 /* UpSampling2D() nearest x2 (L/models/...resnet.py:1669) written into a channel slice. */
 int dj_upsample2x(const float* x, int ldx, float* y, int ldy, int B, int H, int W, int C, void* stream);
 

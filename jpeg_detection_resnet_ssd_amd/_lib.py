@@ -14,6 +14,11 @@ class DjError(RuntimeError):
     pass
 
 
+class CopyPart(Structure):   # dj_copy_part
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("ld_src", c_long), ("ld_dst", c_long), ("rows", c_long),
+                ("cols", c_long), ("beta", c_int)]
+
+
 class ConvDesc(Structure):
     """Mirror of `dj_conv2d_desc` (include/dj_hip.h)."""
     _fields_ = [(n, c_int) for n in (
@@ -56,6 +61,7 @@ SIGNATURES = {
     "dj_conv2d_fwd_addrelu_supported": (c_int, [POINTER(ConvDesc)]),
     "dj_conv2d_nhwc_fwd_addrelu": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, FP, FP, c_int, FP, FP, FP, c_int, c_int, FP,
                                            c_void_p]),
+    "dj_copy2d_multi": (c_int, [POINTER(CopyPart), c_int, c_void_p]),
     "dj_set_fast_path": (None, [c_int]),
     "dj_set_compute_mode": (c_int, [c_int]),
     "dj_get_compute_mode": (c_int, []),

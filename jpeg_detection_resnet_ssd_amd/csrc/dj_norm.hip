@@ -543,6 +543,55 @@ extern "C" int dj_copy2d(const float* src, long ld_src, float* dst, long ld_dst,
   return DJ_OK;
 }
 
+// Up to DJ_COPY_PARTS strided 2-D copies in ONE launch (blockIdx.y = part): Concatenate of several tensors and its
+// gradient are a handful of tiny copies each, whose cost is launch latency, not bytes.
+struct DjCopyParts {
+  dj_copy_part part[DJ_COPY_PARTS];
+};
+
+__global__ __launch_bounds__(256) void dj_copy2d_multi_kernel(DjCopyParts ps) {
+  const dj_copy_part p = ps.part[blockIdx.y];
+  const bool v4 = (p.cols % 4 == 0) && (p.ld_src % 4 == 0) && (p.ld_dst % 4 == 0) && ((((uintptr_t)p.src) & 15) == 0) &&
+                  ((((uintptr_t)p.dst) & 15) == 0);
+  if (v4) {
+    const long cv = p.cols / 4, total = p.rows * cv;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+      long r = i / cv;
+      long c = (i - r * cv) * 4;
+      f32x4 v = *reinterpret_cast<const f32x4*>(p.src + r * p.ld_src + c);
+      f32x4* d = reinterpret_cast<f32x4*>(p.dst + r * p.ld_dst + c);
+      *d = p.beta ? v + *d : v;
+    }
+  } else {
+    const long total = p.rows * p.cols;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+      long r = i / p.cols;
+      long c = i - r * p.cols;
+      float v = p.src[r * p.ld_src + c];
+      float* d = p.dst + r * p.ld_dst + c;
+      *d = p.beta ? v + *d : v;
+    }
+  }
+}
+
+extern "C" int dj_copy2d_multi(const dj_copy_part* parts, int n_parts, void* stream) {
+  DJ_CHECK_ARG(parts && n_parts >= 1 && n_parts <= DJ_COPY_PARTS, "copy2d_multi: 1..%d parts", DJ_COPY_PARTS);
+  DjCopyParts ps;
+  long most = 0;
+  for (int i = 0; i < n_parts; ++i) {
+    const dj_copy_part& p = parts[i];
+    DJ_CHECK_ARG(p.src && p.dst && p.rows > 0 && p.cols > 0 && p.ld_src >= p.cols && p.ld_dst >= p.cols,
+                 "copy2d_multi: bad part %d", i);
+    ps.part[i] = p;
+    long n = p.rows * p.cols;
+    if (n > most) most = n;
+  }
+  hipLaunchKernelGGL(dj_copy2d_multi_kernel, dim3(ew_blocks((most + 3) / 4), n_parts), dim3(256), 0, (hipStream_t)stream,
+                     ps);
+  DJ_CHECK_LAUNCH("dj_copy2d_multi");
+  return DJ_OK;
+}
+
 // UpSampling2D() nearest x2: y[b, 2i+a, 2j+c, :] = x[b, i, j, :]
 __global__ __launch_bounds__(256) void dj_upsample2x_kernel(const float* x, int ldx, float* y, int ldy, int B, int H,
                                                              int W, int C) {

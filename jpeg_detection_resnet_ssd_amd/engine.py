@@ -47,6 +47,27 @@ def call(name, *args):
     check(rc, name)
 
 
+def copy2d_multi(parts):
+    """parts: list of (src, ld_src, dst, ld_dst, rows, cols, beta) -> a launcher issuing as few dj_copy2d_multi
+    launches as possible (descriptor arrays are built once, here)."""
+    lib = _lib.load()
+    chunks = []
+    for i in range(0, len(parts), 8):
+        chunk = parts[i:i + 8]
+        arr = (_lib.CopyPart * len(chunk))()
+        for k, (src, lds, dst, ldd, rows, cols, beta) in enumerate(chunk):
+            arr[k] = _lib.CopyPart(src.data_ptr(), dst.data_ptr(), int(lds), int(ldd), int(rows), int(cols), int(beta))
+        chunks.append((arr, len(chunk)))
+    keep = [(p[0], p[2]) for p in parts]   # the tensors stay alive as long as the launcher does
+
+    def run():
+        stream = torch.cuda.current_stream().cuda_stream
+        for arr, n in chunks:
+            check(lib.dj_copy2d_multi(arr, n, stream), "dj_copy2d_multi")
+    run._keep = keep
+    return run
+
+
 def query(name, *args):
     return check(getattr(_lib.load(), name)(*[int(a) for a in args]), name)
 

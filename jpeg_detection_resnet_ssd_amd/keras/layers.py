@@ -728,6 +728,7 @@ class Concatenate(Layer):
         for n in inner:
             offs.append(o)
             o += n
+        live_parts = []
         for t, n, off in zip(bufs, inner, offs):
             if ax == nd - 1:
                 r, c, ld = rows_of(t)     # may be a channel slice
@@ -736,11 +737,16 @@ class Concatenate(Layer):
                 assert t.is_contiguous()
                 src, lds, rws = t, n, outer
             dst = yflat[:, off:off + n]
-            copy = (lambda src=src, lds=lds, dst=dst, rws=rws, n=n: call("dj_copy2d", src, lds, dst, total, rws, n, 0))
             if getattr(v_of[id(t)], "constant", False):
-                copy()              # constant input (the anchor boxes): its slice of y is written once, now
+                # constant input (the anchor boxes): its slice of y is written once, now
+                call("dj_copy2d", src, lds, dst, total, rws, n, 0)
             else:
-                plan.emit(copy)
+                live_parts.append((src, lds, dst, total, rws, n, 0))
+        if len(live_parts) == 1:
+            src, lds, dst, _, rws, n, _ = live_parts[0]
+            plan.emit(lambda: call("dj_copy2d", src, lds, dst, total, rws, n, 0))
+        elif live_parts:
+            plan.emit(engine.copy2d_multi(live_parts))     # one launch for all members
         out = Value(y, needs_grad=any(v.needs_grad for v in ins), name=self.name)
         out.constant = all(getattr(v, "constant", False) for v in ins)
 
@@ -749,6 +755,7 @@ class Concatenate(Layer):
                 return
             assert out.grad.mask_y is None
             gflat = out.grad.buf.view(outer, total)
+            parts = []
             for v, n, off in zip(ins, inner, offs):
                 if not v.needs_grad:
                     continue
@@ -756,12 +763,15 @@ class Concatenate(Layer):
                 src = gflat[:, off:off + n]
                 if ax == nd - 1:
                     r, c, ld = rows_of(dv)
-                    plan.emit_bwd(lambda src=src, dv=dv, ld=ld, r=r, n=n, beta=beta:
-                                  call("dj_copy2d", src, total, dv, ld, r, n, beta))
+                    parts.append((src, total, dv, ld, r, n, beta))
                 else:
                     assert dv.is_contiguous()
-                    plan.emit_bwd(lambda src=src, dv=dv, n=n, beta=beta:
-                                  call("dj_copy2d", src, total, dv, n, outer, n, beta))
+                    parts.append((src, total, dv, n, outer, n, beta))
+            if len(parts) == 1:
+                src, _, dv, ld, r, n, beta = parts[0]
+                plan.emit_bwd(lambda: call("dj_copy2d", src, total, dv, ld, r, n, beta))
+            elif parts:
+                plan.emit_bwd(engine.copy2d_multi(parts))
 
         plan.on_backward(build_backward)
         return out
