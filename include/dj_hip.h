@@ -113,6 +113,9 @@ int dj_colstats_partial(const float* x, long rows, int C, int ld, float* partial
 int dj_colsum_partial(const float* dy, long rows, int C, int ld, float* partial, void* stream);
 /* out[c] (+)= sum_blk partial[blk][which][c] (accumulated in double). */
 int dj_colreduce_finalize(const float* partial, int nrows, int C, int which, float* out, int beta, void* stream);
+/* out[c] (+)= sum over rows of x[r][c] in one launch -- bias gradients (BiasAddGrad) of the SSD head convs, whose
+ * gradient tensors have at most a few thousand rows. */
+int dj_colsum_direct(const float* x, long rows, int C, int ld, float* out, int beta, void* stream);
 
 /* ---- keras.layers.BatchNormalization(axis=3) (Keras 2.2.4 defaults eps 1e-3, momentum 0.99) ----
  * Training forward = statistics (conv epilogue `stats` or dj_colstats_partial) -> dj_bn_train_finalize

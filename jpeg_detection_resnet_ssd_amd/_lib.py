@@ -61,6 +61,7 @@ SIGNATURES = {
     "dj_conv2d_fwd_addrelu_supported": (c_int, [POINTER(ConvDesc)]),
     "dj_conv2d_nhwc_fwd_addrelu": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, FP, FP, c_int, FP, FP, FP, c_int, c_int, FP,
                                            c_void_p]),
+    "dj_colsum_direct": (c_int, [FP, c_long, c_int, c_int, FP, c_int, c_void_p]),
     "dj_copy2d_multi": (c_int, [POINTER(CopyPart), c_int, c_void_p]),
     "dj_set_fast_path": (None, [c_int]),
     "dj_set_compute_mode": (c_int, [c_int]),

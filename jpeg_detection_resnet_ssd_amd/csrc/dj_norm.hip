@@ -254,6 +254,50 @@ extern "C" int dj_colreduce_finalize(const float* partial, int nrows, int C, int
   return DJ_OK;
 }
 
+// out[c] (+)= sum_r x[r][c] in ONE launch (1024 threads = 16 columns x 64 row lanes, double accumulation): the bias
+// gradients of the SSD head convolutions have at most a few thousand rows, where two launches cost more than the sum
+__global__ __launch_bounds__(DJ_FIN_THREADS) void dj_colsum_direct_kernel(const float* x, long rows, int C, int ld, float* out,
+                                                                          int beta) {
+  __shared__ double red[DJ_FIN_LANES][DJ_FIN_CH + 1];
+  const int tx = threadIdx.x & (DJ_FIN_CH - 1), ty = threadIdx.x / DJ_FIN_CH;
+  const int c = blockIdx.x * DJ_FIN_CH + tx;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (c < C) {
+    long r = ty;
+    for (; r + 3 * DJ_FIN_LANES < rows; r += 4 * DJ_FIN_LANES) {
+      const float* p = x + r * ld + c;
+      float v0 = p[0], v1 = p[(long)DJ_FIN_LANES * ld], v2 = p[(long)2 * DJ_FIN_LANES * ld], v3 = p[(long)3 * DJ_FIN_LANES * ld];
+      a0 += (double)v0;
+      a1 += (double)v1;
+      a2 += (double)v2;
+      a3 += (double)v3;
+    }
+    for (; r < rows; r += DJ_FIN_LANES) a0 += (double)x[r * ld + c];
+  }
+  red[ty][tx] = a0 + a1 + a2 + a3;
+  __syncthreads();
+  if (ty < 8) {
+    double a = red[ty][tx];
+    for (int j = ty + 8; j < DJ_FIN_LANES; j += 8) a += red[j][tx];
+    red[ty][tx] = a;
+  }
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    double a = red[0][tx];
+    for (int j = 1; j < 8; ++j) a += red[j][tx];
+    float v = (float)a;
+    out[c] = beta ? out[c] + v : v;
+  }
+}
+
+extern "C" int dj_colsum_direct(const float* x, long rows, int C, int ld, float* out, int beta, void* stream) {
+  DJ_CHECK_ARG(x && out && rows > 0 && C > 0 && ld >= C, "colsum_direct: bad arguments");
+  hipLaunchKernelGGL(dj_colsum_direct_kernel, dim3(dj_cdiv(C, DJ_FIN_CH)), dim3(DJ_FIN_THREADS), 0, (hipStream_t)stream, x,
+                     rows, C, ld, out, beta);
+  DJ_CHECK_LAUNCH("dj_colsum_direct");
+  return DJ_OK;
+}
+
 // ---------------------------------------------------------------------------------
 // BatchNormalization, training mode: finalize statistics -> (scale, shift)
 // ---------------------------------------------------------------------------------

@@ -209,8 +209,12 @@ def _materialised(v, who, plan=None, allow_pad=False):
 
 
 def _bias_grad(plan, dy, spec):
-    """dbias = column sum of dy (two-stage)."""
+    """dbias = column sum of dy (one launch for short tensors, two-stage otherwise)."""
     rows, c, ld = rows_of(dy)
+    if rows <= 8192:
+        plan.emit_bwd(lambda: call("dj_colsum_direct", dy, rows, c, ld, spec.grad, 0))
+        plan.note_grad(spec)
+        return
     nr = query("dj_reduce_rows", rows)
     partial = plan.empty(nr, 2, c)
     plan.emit_bwd(lambda: call("dj_colsum_partial", dy, rows, c, ld, partial))

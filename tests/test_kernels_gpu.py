@@ -278,3 +278,13 @@ def test_sgd_keras_formula(nesterov, cuda, E):
     torch.cuda.synchronize()
     assert close(pd, pn, rel=1e-6) and close(vd, vn, rel=1e-6)
     assert abs(float(ss) - float((p.double() ** 2).sum())) <= 1e-4 * float((p.double() ** 2).sum())
+
+
+@pytest.mark.parametrize("rows,c,ld", [(3200, 126, 126), (800, 24, 24), (37, 5, 9), (8192, 512, 512)])
+def test_colsum_direct(rows, c, ld, cuda, E):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(rows, ld, generator=g)
+    out = torch.full((c,), 1.5, device=cuda)
+    E.call("dj_colsum_direct", x.to(cuda), rows, c, ld, out, 1)
+    torch.cuda.synchronize()
+    assert close(out.cpu(), 1.5 + x[:, :c].double().sum(0), rel=1e-6)
