@@ -68,6 +68,13 @@ def copy2d_multi(parts):
     return run
 
 
+def tuned_splits(direction, desc):
+    """Split-K factor the in-tree table registers for this geometry (None: not in the table)."""
+    names = [n for n, _ in _lib.ConvDesc._fields_][:15]
+    known = _tune_db().get(",".join(str(int(v)) for v in ((direction,) + tuple(getattr(desc, n) for n in names))))
+    return None if known is None else int(known[1])
+
+
 def query(name, *args):
     return check(getattr(_lib.load(), name)(*[int(a) for a in args]), name)
 
@@ -162,6 +169,7 @@ class Plan(object):
         self.grads_cleared = False   # True: the first backward launch zeroes the model's whole flat gradient buffer
         # weight-gradient GEMMs only feed the optimizer, so they run on a second HIP stream and fill the CUs the
         # data-gradient chain leaves idle at its tile-quantisation tails (DJ_SIDE_WGRAD=0 keeps one stream)
+        self._arena, self._arena_used, self._arena_high = [], 0, {}
         self.targets_event = None    # set while the side stream encodes y_true (Model._upload), cleared by the loss
         self.side_stream = None
         self.side_enabled = True     # cleared while kernels are timed one by one (bench.py)
@@ -175,6 +183,30 @@ class Plan(object):
         t = torch.empty(*shape, dtype=torch.float32, device=self.device)
         self.bytes_allocated += t.numel() * 4
         return t
+
+    def zeroed_each_step(self, *shape):
+        """A buffer out of an arena that ONE memset clears at the start of every step: for gradient tensors whose first
+        writer accumulates with atomics (split-K) or scatters (stride-2 1x1 dgrad) and would otherwise need its own
+        memset launch in the middle of the backward chain."""
+        n = 1
+        for d in shape:
+            n *= int(d)
+        n_pad = (n + 63) // 64 * 64
+        chunk = 64 << 20     # floats per arena chunk (256 MB)
+        if not self._arena or self._arena_used + n_pad > self._arena[-1].numel():
+            self._arena.append(torch.zeros(max(chunk, n_pad), dtype=torch.float32, device=self.device))
+            self._arena_used = 0
+            self.bytes_allocated += self._arena[-1].numel() * 4
+            if len(self._arena) == 1:
+                self.fwd.insert(0, self._clear_arena)
+        t = self._arena[-1][self._arena_used:self._arena_used + n].view(*shape)
+        self._arena_used += n_pad
+        self._arena_high[len(self._arena) - 1] = self._arena_used
+        return t
+
+    def _clear_arena(self):
+        for i, a in enumerate(self._arena):
+            a[:self._arena_high[i]].zero_()
 
     def zeros(self, *shape):
         t = torch.zeros(*shape, dtype=torch.float32, device=self.device)
@@ -295,12 +327,16 @@ class Plan(object):
         self._bwd_builders = []
 
     # ---- gradients ------------------------------------------------------------
-    def grad_of(self, v):
-        """-> (buffer, beta).  beta = 0 for the first writer in backward execution order."""
+    def grad_of(self, v, zeroed=False):
+        """-> (buffer, beta).  beta = 0 for the first writer in backward execution order.  zeroed=True: a first writer
+        that would have to clear the buffer itself gets one that is already zero (see zeroed_each_step) and beta = 1."""
         if v.alias_of is not None:
-            buf, beta = self.grad_of(v.alias_of)
+            buf, beta = self.grad_of(v.alias_of, zeroed)
             return v.alias_view(buf), beta
         if v.grad is None:
+            if zeroed:
+                v.grad = GradRef(self.zeroed_each_step(*v.buf.shape))
+                return v.grad.buf, 1
             v.grad = GradRef(self.empty(*v.buf.shape))
             return v.grad.buf, 0
         assert v.grad.mask_y is None, "cannot accumulate into a masked gradient reference"

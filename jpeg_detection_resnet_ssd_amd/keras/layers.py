@@ -319,7 +319,11 @@ class Conv2D(Layer):
                                side=True)
                 plan.note_grad(self.kernel)
             if x.needs_grad:
-                dx, beta = plan.grad_of(x)
+                # a first-writer dgrad that accumulates with atomics (split-K) or scatters (stride-2 1x1) clears dx with
+                # a memset of its own; hand it a buffer from the arena that one memset clears per step instead
+                strided_1x1 = self.kernel_size == (1, 1) and self.strides != (1, 1)
+                own_memset = strided_1x1 or (engine.tuned_splits(1, desc) or 1) > 1
+                dx, beta = plan.grad_of(x, zeroed=own_memset and os.environ.get("DJ_ZERO_ARENA", "1") != "0")
                 plan.emit_conv(1, desc, lambda: Kn.conv2d_dgrad(desc, dy, wgt, dx, None, bool(beta)), backward=True)
 
         plan.on_backward(build_backward)
