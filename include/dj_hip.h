@@ -53,6 +53,10 @@ int dj_conv2d_fwd_stats_rows(const dj_conv2d_desc* d);
  *     runs between two convs (L/models/...resnet.py:80-81,90-91) folded into the load.
  *   stats (optional): per-row-tile column sums / sums of squares of conv(x,w) WITHOUT bias,
  *     consumed by dj_bn_finalize (training-mode BatchNormalization statistics). */
+/* `relu` argument of dj_conv2d_nhwc_fwd: DJ_CONV_RELU = fused ReLU epilogue; DJ_CONV_Y_ZEROED = the caller guarantees y is
+ * all zeros on entry, so a split-K launch (atomic accumulation) does not clear it first. */
+#define DJ_CONV_RELU 1
+#define DJ_CONV_Y_ZEROED 2
 int dj_conv2d_nhwc_fwd(const dj_conv2d_desc* d, const float* x, const float* w, const float* bias,
                        float* y, const float* pro_scale, const float* pro_shift, int pro_relu,
                        int relu, float* stats, void* stream);

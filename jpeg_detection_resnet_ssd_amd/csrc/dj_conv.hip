@@ -211,6 +211,8 @@ static int conv_fwd_impl(const dj_conv2d_desc* d, const float* x, const float* w
   p.ldb = d->out_c;
   p.ldc = d->ld_y;
   p.cmap = 0;
+  const bool y_zeroed = (relu & DJ_CONV_Y_ZEROED) != 0;
+  relu &= DJ_CONV_RELU;
   p.relu = relu;
   p.vecA = (d->in_c % 4 == 0) && (d->ld_x % 4 == 0) && aligned16(x) &&
            (!pro_scale || (aligned16(pro_scale) && aligned16(pro_shift)));
@@ -236,10 +238,12 @@ static int conv_fwd_impl(const dj_conv2d_desc* d, const float* x, const float* w
   if (splits > 1) {
     p.atomic = 1;
     p.relu = 0;
-    hipError_t e = hipMemset2DAsync(y, (size_t)d->ld_y * 4, 0, (size_t)d->out_c * 4, (size_t)p.M, s);
-    if (e != hipSuccess) {
-      dj_set_error("conv fwd: memset: %s", hipGetErrorString(e));
-      return DJ_ERR_HIP;
+    if (!y_zeroed) {
+      hipError_t e = hipMemset2DAsync(y, (size_t)d->ld_y * 4, 0, (size_t)d->out_c * 4, (size_t)p.M, s);
+      if (e != hipSuccess) {
+        dj_set_error("conv fwd: memset: %s", hipGetErrorString(e));
+        return DJ_ERR_HIP;
+      }
     }
   }
   if (rz.res) {

@@ -270,7 +270,6 @@ class Conv2D(Layer):
             padding = x.pad
         desc = Kn.make_conv_desc(b, h, w, cin, self.filters, self.kernel_size, self.strides, padding,
                                  self.dilation_rate)
-        y = plan.empty(b, desc.out_h, desc.out_w, self.filters)
         relu = self.activation == "relu"
         wgt, bias = self.kernel.param, (self.bias.param if self.bias is not None else None)
         pro = (x.scale, x.shift, x.relu) if x.is_affine else (None, None, False)
@@ -279,6 +278,11 @@ class Conv2D(Layer):
         if (plan.training and not relu and len(consumers) == 1 and isinstance(consumers[0], BatchNormalization)):
             nrows = Kn.conv2d_stats_rows(desc)
             stats = plan.empty(nrows, 2, self.filters)
+        # a split-K forward (the small-M head convs) accumulates with atomics into a cleared y: take y from the arena
+        # that one memset clears per step rather than clearing it inside the launch
+        y_zeroed = (stats is None and (engine.tuned_splits(0, desc) or 1) > 1
+                    and os.environ.get("DJ_ZERO_ARENA", "1") != "0")
+        y = (plan.zeroed_each_step if y_zeroed else plan.empty)(b, desc.out_h, desc.out_w, self.filters)
         xbuf = x.buf
         pend = getattr(x, "pending_add", None)
         if pend is not None:
@@ -291,7 +295,7 @@ class Conv2D(Layer):
             x.pending_add = None
         else:
             plan.emit_conv(4 if stats is not None else 0, desc,
-                           lambda: Kn.conv2d_fwd(desc, xbuf, wgt, bias, y, pro[0], pro[1], pro[2], relu, stats))
+                           lambda: Kn.conv2d_fwd(desc, xbuf, wgt, bias, y, pro[0], pro[1], pro[2], relu, stats, y_zeroed))
         out = Value(y, needs_grad=True, name=self.name)
         if stats is not None:
             out.conv_stats = (stats, stats.shape[0], bias)

@@ -79,11 +79,14 @@ def conv2d_stats_rows(desc):
     return check(_lib.load().dj_conv2d_fwd_stats_rows(desc), "dj_conv2d_fwd_stats_rows")
 
 
-def conv2d_fwd(desc, x, w, bias, y, pro_scale=None, pro_shift=None, pro_relu=False, relu=False, stats=None):
+def conv2d_fwd(desc, x, w, bias, y, pro_scale=None, pro_shift=None, pro_relu=False, relu=False, stats=None,
+               y_zeroed=False):
+    """`y_zeroed`: y is all zeros on entry (a split-K launch then skips its own memset)."""
     d = _desc_for(desc, x, y)
     assert w.is_contiguous() and tuple(w.shape) == (d.kernel_h, d.kernel_w, d.in_c, d.out_c)
     check(_lib.load().dj_conv2d_nhwc_fwd(d, ptr(x), ptr(w), ptr(bias), ptr(y), ptr(pro_scale), ptr(pro_shift),
-                                         int(pro_relu), int(relu), ptr(stats), _stream()), "dj_conv2d_nhwc_fwd")
+                                         int(pro_relu), int(bool(relu)) | (2 if y_zeroed else 0), ptr(stats), _stream()),
+          "dj_conv2d_nhwc_fwd")
     return y
 
 

@@ -93,4 +93,6 @@ def test_two_rank_step_matches_gradient_averaging(cuda, monkeypatch):
     torch.cuda.synchronize()
     ref = model.flat_trainable.detach().cpu().numpy()
     err = np.abs(ref - w0).max() / np.abs(ref).max()
-    assert err <= 1e-5, err
+    # split-K gradient GEMMs accumulate with fp32 atomics in arrival order: two runs of the same step differ by a few 1e-6,
+    # occasionally 5e-5 after two steps; a missing 1/world or a dropped bucket shows up at 1e-2 and above
+    assert err <= 2e-4, err
