@@ -81,6 +81,33 @@ int dj_conv2d_nhwc_fwd_addrelu(const dj_conv2d_desc* d, const float* x, const fl
                                const float* res_scale, const float* res_shift, float* sum_out, int ld_sum, int relu,
                                float* stats, void* stream);
 
+/* Convolution + the training-mode BatchNormalization that follows it (keras BatchNormalization(axis=3) after Conv2D,
+ * L/models/keras_ssd300_dct_j2d_resnet.py:66-99): the conv epilogue adds each tile's column sums / sums of squares to
+ * `acc` with fp64 atomics, the workgroup that finishes last turns them into scale = gamma/sqrt(var+eps),
+ * shift = beta - mean*scale, save_mean / save_invstd (for the backward pass) and the momentum update of the moving
+ * statistics (Bessel-corrected variance), and leaves acc / ticket zero again.  Replaces conv `stats` +
+ * dj_bn_train_finalize: no launch between the conv and its consumer.  `acc` = DJ_BN_ACC_REPLICAS*2*out_c doubles and
+ * `ticket` = one unsigned, zero before the first launch.  res != NULL selects the residual-add prologue of
+ * dj_conv2d_nhwc_fwd_addrelu. */
+#define DJ_BN_ACC_REPLICAS 16
+typedef struct dj_bn_train {
+  double* acc;
+  unsigned* ticket;
+  const float* gamma;
+  const float* beta;
+  float* moving_mean; /* NULL: no moving-statistics update */
+  float* moving_var;
+  float* scale;
+  float* shift;
+  float* save_mean;
+  float* save_invstd;
+  float eps, momentum;
+} dj_bn_train;
+int dj_conv2d_nhwc_fwd_bn(const dj_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y,
+                          const float* pro_scale, const float* pro_shift, int pro_relu, const float* res, int ld_res,
+                          const float* res_scale, const float* res_shift, float* sum_out, int ld_sum,
+                          const dj_bn_train* bn, void* stream);
+
 /* Debug/test switch: 0 forces the generic (branchy, any-shape) implicit-GEMM kernel, 1 (default) lets the
  * launcher pick the branch-free buffer-load kernel whenever its alignment preconditions hold. */
 void dj_set_fast_path(int enable);

@@ -14,6 +14,12 @@ class DjError(RuntimeError):
     pass
 
 
+class BnTrain(Structure):   # dj_bn_train
+    _fields_ = [("acc", c_void_p), ("ticket", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
+                ("moving_mean", c_void_p), ("moving_var", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
+                ("save_mean", c_void_p), ("save_invstd", c_void_p), ("eps", c_float), ("momentum", c_float)]
+
+
 class CopyPart(Structure):   # dj_copy_part
     _fields_ = [("src", c_void_p), ("dst", c_void_p), ("ld_src", c_long), ("ld_dst", c_long), ("rows", c_long),
                 ("cols", c_long), ("beta", c_int)]
@@ -63,6 +69,8 @@ SIGNATURES = {
                                            c_void_p]),
     "dj_colsum_direct": (c_int, [FP, c_long, c_int, c_int, FP, c_int, c_void_p]),
     "dj_copy2d_multi": (c_int, [POINTER(CopyPart), c_int, c_void_p]),
+    "dj_conv2d_nhwc_fwd_bn": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, FP, c_int, FP, c_int, FP, FP, FP, c_int,
+                                      POINTER(BnTrain), c_void_p]),
     "dj_set_fast_path": (None, [c_int]),
     "dj_set_compute_mode": (c_int, [c_int]),
     "dj_get_compute_mode": (c_int, []),

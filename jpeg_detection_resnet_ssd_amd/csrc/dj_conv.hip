@@ -5,6 +5,7 @@
 #include <map>
 #include <mutex>
 #include <array>
+#include <algorithm>
 
 static thread_local char g_err[512] = "";
 void dj_set_error(const char* fmt, ...) {
@@ -173,6 +174,7 @@ extern "C" int dj_conv2d_fwd_stats_rows(const dj_conv2d_desc* d) {
 }
 
 struct FwdResidual {
+  const dj_bn_train* bn = nullptr;   // finish the following BatchNormalization inside the launch
   const float* res = nullptr;
   int ld_res = 0;
   const float* res_scale = nullptr;
@@ -229,10 +231,34 @@ static int conv_fwd_impl(const dj_conv2d_desc* d, const float* x, const float* w
     p.sum_bytes = rz.sum_out ? extent_bytes((long)d->batch * d->in_h * d->in_w, rz.ld_sum, d->in_c) : 0;
   }
   p.b_bytes = extent_bytes((long)p.K, d->out_c, d->out_c);
+  if (rz.bn) {
+    const dj_bn_train& b = *rz.bn;
+    DJ_CHECK_ARG(b.acc && b.ticket && b.gamma && b.beta && b.scale && b.shift && b.save_mean && b.save_invstd,
+                 "conv fwd (BN): null pointer in dj_bn_train");
+    DJ_CHECK_ARG((b.moving_mean == nullptr) == (b.moving_var == nullptr), "conv fwd (BN): moving stats come together");
+    DJ_CHECK_ARG(stats == nullptr && !relu, "conv fwd (BN): no partial statistics / fused ReLU together with the fused finalize");
+    p.bn_acc = b.acc;
+    // one copy of the accumulators per 8192 GEMM rows: the big-M layers are the ones whose hundreds of workgroups
+    // would otherwise queue on the same 2*N addresses
+    p.bn_replicas = (int)std::min<long>(DJ_BN_ACC_REPLICAS, std::max<long>(1, p.M / 8192));
+    p.bn_ticket = b.ticket;
+    p.bn_gamma = b.gamma;
+    p.bn_beta = b.beta;
+    p.bn_moving_mean = b.moving_mean;
+    p.bn_moving_var = b.moving_var;
+    p.bn_scale = b.scale;
+    p.bn_shift = b.shift;
+    p.bn_save_mean = b.save_mean;
+    p.bn_save_invstd = b.save_invstd;
+    p.bn_eps = b.eps;
+    p.bn_momentum = b.momentum;
+    p.bn_count = (double)p.M;
+  }
+  const bool wants_stats = stats != nullptr || rz.bn != nullptr;
   int splits = 1;
-  int cfg = choose_cfg(p.M, p.N, p.K, stats == nullptr, &splits);
-  tune_lookup(stats ? 4 : 0, d, &cfg, &splits);
-  if (stats) splits = 1;
+  int cfg = choose_cfg(p.M, p.N, p.K, !wants_stats, &splits);
+  tune_lookup(wants_stats ? 4 : 0, d, &cfg, &splits);
+  if (wants_stats) splits = 1;
   p.kchunk = dj_cdiv(dj_cdiv(p.K, splits), DJ_BK) * DJ_BK;
   splits = dj_cdiv(p.K, p.kchunk);
   if (splits > 1) {
@@ -266,8 +292,35 @@ extern "C" int dj_conv2d_nhwc_fwd(const dj_conv2d_desc* d, const float* x, const
   return conv_fwd_impl(d, x, w, bias, y, pro_scale, pro_shift, pro_relu, relu, stats, FwdResidual(), stream);
 }
 
-// 1x1 stride-1 convolution whose input is relu(x*pro_scale+pro_shift + res*res_scale+res_shift): the residual Add + ReLU
-// of a bottleneck block evaluated while the A tile is staged; `sum_out` (optional) receives that input tensor.
+// Forward conv whose only consumer is a training-mode BatchNormalization: that layer's statistics, scale/shift and
+// moving averages are produced by the same launch (res == NULL: plain input; else the residual-add prologue above).
+extern "C" int dj_conv2d_nhwc_fwd_bn(const dj_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y,
+                                     const float* pro_scale, const float* pro_shift, int pro_relu, const float* res,
+                                     int ld_res, const float* res_scale, const float* res_shift, float* sum_out,
+                                     int ld_sum, const dj_bn_train* bn, void* stream) {
+  DJ_CHECK_ARG(bn != nullptr, "conv fwd (BN): dj_bn_train is required");
+  FwdResidual rz;
+  rz.bn = bn;
+  if (res) {
+    DJ_CHECK_ARG(d && dj_conv2d_fwd_addrelu_supported(d), "conv fwd (BN, residual add): needs a 1x1 stride-1 unpadded conv "
+                                                           "with in_c %% 32 == 0");
+    DJ_CHECK_ARG(pro_scale && pro_shift, "conv fwd (BN, residual add): pro_scale and pro_shift are required");
+    DJ_CHECK_ARG((res_scale == nullptr) == (res_shift == nullptr), "conv fwd (BN, residual add): res_scale/res_shift");
+    DJ_CHECK_ARG(ld_res >= d->in_c && ld_res % 4 == 0 && (!sum_out || (ld_sum >= d->in_c && ld_sum % 4 == 0)),
+                 "conv fwd (BN, residual add): bad ld_res / ld_sum");
+    DJ_CHECK_ARG(aligned16(res) && aligned16(sum_out) && aligned16(res_scale) && aligned16(res_shift),
+                 "conv fwd (BN, residual add): tensors must be 16-byte aligned");
+    rz.res = res;
+    rz.ld_res = ld_res;
+    rz.res_scale = res_scale;
+    rz.res_shift = res_shift;
+    rz.sum_out = sum_out;
+    rz.ld_sum = ld_sum;
+    pro_relu = 1;
+  }
+  return conv_fwd_impl(d, x, w, bias, y, pro_scale, pro_shift, pro_relu, 0, nullptr, rz, stream);
+}
+
 extern "C" int dj_conv2d_fwd_addrelu_supported(const dj_conv2d_desc* d) {
   if (check_desc(d)) return 0;
   return d->kernel_h == 1 && d->kernel_w == 1 && d->stride_h == 1 && d->stride_w == 1 && d->pad_top == 0 &&

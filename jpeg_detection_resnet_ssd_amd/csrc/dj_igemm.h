@@ -57,6 +57,22 @@ struct DjIgemmParams {
   const float* pro_shift2;
   float* sum_out;
   int ldsrc2, ld_sum, a2_bytes, sum_bytes;
+  // BatchNormalization (training) finished inside the producing convolution: every workgroup adds its column sums to
+  // bn_acc with fp64 atomics, takes a ticket, and the last one turns the totals into scale / shift / saved and moving
+  // statistics and clears bn_acc / bn_ticket again -- no separate finalize launch between this conv and its consumer
+  double* bn_acc;           // [bn_replicas][2][N], zero on entry
+  int bn_replicas;          // workgroups spread their atomics over this many copies (same-address contention)
+  unsigned* bn_ticket;      // zero on entry
+  const float* bn_gamma;
+  const float* bn_beta;
+  float* bn_moving_mean;    // may be null (then bn_moving_var is null too)
+  float* bn_moving_var;
+  float* bn_scale;
+  float* bn_shift;
+  float* bn_save_mean;
+  float* bn_save_invstd;
+  float bn_eps, bn_momentum;
+  double bn_count;
 };
 
 template <int BM, int BN, int WM, int WN, int AM, int BMD>
@@ -120,7 +136,7 @@ __device__ __forceinline__ void dj_igemm_epilogue(const DjIgemmParams& p, f32x16
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lh = lane >> 5;
-  if (p.stats) {
+  if (p.stats || p.bn_acc) {
     // per-column sum and sum of squares of the raw accumulator over this tile's rows
     float* red = smem;  // [2][WM][BN]
 #pragma unroll
@@ -143,10 +159,26 @@ __device__ __forceinline__ void dj_igemm_epilogue(const DjIgemmParams& p, f32x16
       }
     }
     __syncthreads();
+    if (p.bn_acc) {
+      for (int col = tid; col < BN; col += 256) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          s += red[(0 * WM + w) * BN + col];
+          q += red[(1 * WM + w) * BN + col];
+        }
+        int n = n0 + col;
+        if (n < p.N) {
+          double* acc = p.bn_acc + (size_t)(blockIdx.x % (unsigned)p.bn_replicas) * 2 * p.N;
+          unsafeAtomicAdd(acc + n, (double)s);
+          unsafeAtomicAdd(acc + p.N + n, (double)q);
+        }
+      }
+    }
     // one partial row per 64 GEMM rows, whatever the tile shape: [ceil(M/64)][2][N]
     constexpr int GROUPS = BM / 64;          // 64-row groups in this tile
     constexpr int WPG = WM / GROUPS;         // wave rows per group
-    for (int idx = tid; idx < GROUPS * BN; idx += 256) {
+    for (int idx = tid; p.stats && idx < GROUPS * BN; idx += 256) {
       int g = idx / BN, col = idx - g * BN;
       float s = 0.f, q = 0.f;
 #pragma unroll
@@ -195,6 +227,50 @@ __device__ __forceinline__ void dj_igemm_epilogue(const DjIgemmParams& p, f32x16
           *dst = v;
         }
       }
+    }
+  }
+  if (p.bn_acc) {
+    // Take a ticket once our atomics have been performed; the workgroup that takes the last one sees every other
+    // workgroup's sums.  Not __threadfence(): on gfx950 an agent-scope release is `buffer_wbl2 sc1` + `buffer_inv sc1`,
+    // i.e. every workgroup would write back and invalidate its XCD's L2 (measured: 1172 -> 880 img/s on the step).
+    // Only the accumulators need ordering, they are touched by device-scope atomics / sc1 accesses alone, and those
+    // are complete when vmcnt reaches zero.
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      unsigned t = atomicAdd(p.bn_ticket, 1u);
+      s_last = (t == gridDim.x * gridDim.y - 1u) ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_last) {
+      for (int c = tid; c < p.N; c += 256) {
+        double S = 0.0, Q = 0.0;
+        for (int r = 0; r < p.bn_replicas; ++r) {
+          double* acc = p.bn_acc + (size_t)r * 2 * p.N;
+          S += __hip_atomic_load(acc + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          Q += __hip_atomic_load(acc + p.N + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(acc + c, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(acc + p.N + c, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        double m = S / p.bn_count;
+        double var = Q / p.bn_count - m * m;
+        if (var < 0.0) var = 0.0;
+        // the sums were taken on the accumulator before the conv bias: it shifts the mean only
+        double mean = m + (p.bias ? (double)p.bias[c] : 0.0);
+        float invstd = (float)(1.0 / sqrt(var + (double)p.bn_eps));
+        float sc = p.bn_gamma[c] * invstd;
+        p.bn_scale[c] = sc;
+        p.bn_shift[c] = p.bn_beta[c] - (float)mean * sc;
+        p.bn_save_mean[c] = (float)mean;
+        p.bn_save_invstd[c] = invstd;
+        if (p.bn_moving_mean) {
+          double unbiased = var * (p.bn_count / (p.bn_count > 1.0 ? p.bn_count - 1.0 : 1.0));
+          p.bn_moving_mean[c] = p.bn_moving_mean[c] * p.bn_momentum + (float)mean * (1.f - p.bn_momentum);
+          p.bn_moving_var[c] = p.bn_moving_var[c] * p.bn_momentum + (float)unbiased * (1.f - p.bn_momentum);
+        }
+      }
+      if (tid == 0) __hip_atomic_store(p.bn_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }

@@ -532,7 +532,11 @@ __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmPa
     }
     __syncthreads();
     if (kg == 1) {
-      if (p.stats) __syncthreads();   // matches the one barrier of the statistics epilogue
+      if (p.stats || p.bn_acc) __syncthreads();   // matches the barrier of the statistics epilogue
+      if (p.bn_acc) {                              // ... and the two of the in-kernel BatchNormalization finalize
+        __syncthreads();
+        __syncthreads();
+      }
       return;
     }
 #pragma unroll

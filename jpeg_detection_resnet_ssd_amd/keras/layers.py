@@ -273,14 +273,26 @@ class Conv2D(Layer):
         relu = self.activation == "relu"
         wgt, bias = self.kernel.param, (self.bias.param if self.bias is not None else None)
         pro = (x.scale, x.shift, x.relu) if x.is_affine else (None, None, False)
-        stats = None
+        stats = fused_bn = None
         consumers = model.consumers_of(self.outbound[0])
         if (plan.training and not relu and len(consumers) == 1 and isinstance(consumers[0], BatchNormalization)):
-            nrows = Kn.conv2d_stats_rows(desc)
-            stats = plan.empty(nrows, 2, self.filters)
+            if os.environ.get("DJ_FUSE_BNFIN", "0") == "1":
+                # opt-in: the conv's last workgroup turns the column sums into the BatchNormalization coefficients itself
+                # (fp64 accumulators + a ticket, both left zero by that workgroup).  Saves the finalize launch but every
+                # workgroup pays a ticket round trip: 0.6 % SLOWER on the SSD300 step, hence off
+                bnl, c = consumers[0], self.filters
+                fused_bn = dict(scale=plan.empty(c), shift=plan.empty(c), mean=plan.empty(c), invstd=plan.empty(c))
+                acc = torch.zeros(Kn.BN_ACC_REPLICAS * 2 * c, dtype=torch.float64, device=plan.device)
+                ticket = torch.zeros(1, dtype=torch.int32, device=plan.device)
+                bn_arg = Kn.make_bn_train(acc, ticket, bnl.gamma.param, bnl.beta.param, bnl.moving_mean.param,
+                                          bnl.moving_variance.param, fused_bn["scale"], fused_bn["shift"],
+                                          fused_bn["mean"], fused_bn["invstd"], bnl.epsilon, bnl.momentum)
+            else:
+                nrows = Kn.conv2d_stats_rows(desc)
+                stats = plan.empty(nrows, 2, self.filters)
         # a split-K forward (the small-M head convs) accumulates with atomics into a cleared y: take y from the arena
         # that one memset clears per step rather than clearing it inside the launch
-        y_zeroed = (stats is None and (engine.tuned_splits(0, desc) or 1) > 1
+        y_zeroed = (stats is None and fused_bn is None and (engine.tuned_splits(0, desc) or 1) > 1
                     and os.environ.get("DJ_ZERO_ARENA", "1") != "0")
         y = (plan.zeroed_each_step if y_zeroed else plan.empty)(b, desc.out_h, desc.out_w, self.filters)
         xbuf = x.buf
@@ -290,15 +302,22 @@ class Conv2D(Layer):
             # writes it to xbuf for everybody else (Add.lower picked this layer because it runs first)
             assert pend["consumer"] is self, "a residual sum must be materialised by its first consumer"
             zb, zs, zt, rb, rs, rt = pend["z"], pend["z_scale"], pend["z_shift"], pend["res"], pend["res_scale"], pend["res_shift"]
-            plan.emit_conv(4 if stats is not None else 0, desc,
-                           lambda: Kn.conv2d_fwd_addrelu(desc, zb, wgt, bias, y, zs, zt, rb, rs, rt, xbuf, relu, stats))
+            if fused_bn is not None:
+                plan.emit_conv(4, desc, lambda: Kn.conv2d_fwd_bn(desc, zb, wgt, bias, y, bn_arg, zs, zt, True, rb, rs, rt,
+                                                                 xbuf))
+            else:
+                plan.emit_conv(4 if stats is not None else 0, desc,
+                               lambda: Kn.conv2d_fwd_addrelu(desc, zb, wgt, bias, y, zs, zt, rb, rs, rt, xbuf, relu, stats))
             x.pending_add = None
+        elif fused_bn is not None:
+            plan.emit_conv(4, desc, lambda: Kn.conv2d_fwd_bn(desc, xbuf, wgt, bias, y, bn_arg, pro[0], pro[1], pro[2]))
         else:
             plan.emit_conv(4 if stats is not None else 0, desc,
                            lambda: Kn.conv2d_fwd(desc, xbuf, wgt, bias, y, pro[0], pro[1], pro[2], relu, stats, y_zeroed))
         out = Value(y, needs_grad=True, name=self.name)
         if stats is not None:
             out.conv_stats = (stats, stats.shape[0], bias)
+        out.bn_done = fused_bn
 
         def build_backward():
             if out.grad is None:
@@ -309,7 +328,7 @@ class Conv2D(Layer):
                 rows, c, ld = rows_of(dy)
                 plan.emit_bwd(lambda: call("dj_relu_bwd", dy, ld, y, c, dy, ld, rows, c, 0))
             if self.bias is not None and self.bias.trainable:
-                if stats is not None:
+                if stats is not None or fused_bn is not None:
                     # the only consumer is a training-mode BatchNormalization: it subtracts the batch mean, so
                     # d loss / d bias = sum(dz) is identically zero (TF's autodiff returns rounding noise);
                     # the gradient buffer is zero-initialised and simply left untouched
@@ -518,7 +537,8 @@ class BatchNormalization(Layer):
         x = ins[0]
         z = _materialised(x, self.name, plan)
         rows, c, ld = rows_of(z)
-        scale, shift = plan.empty(c), plan.empty(c)
+        done = getattr(x, "bn_done", None) if plan.training else None
+        scale, shift = (done["scale"], done["shift"]) if done else (plan.empty(c), plan.empty(c))
         gamma, beta = self.gamma.param, self.beta.param
         mm, mv = self.moving_mean.param, self.moving_variance.param
         out = Value(z, scale=scale, shift=shift, relu=False, needs_grad=True, name=self.name)
@@ -527,15 +547,18 @@ class BatchNormalization(Layer):
         if not plan.training:
             plan.emit(lambda: call("dj_bn_infer_coeffs", gamma, beta, mm, mv, self.epsilon, scale, shift, c))
             return out
-        mean, invstd = plan.empty(c), plan.empty(c)
-        if x.conv_stats is not None:
-            partial, nrows, conv_bias = x.conv_stats
+        if done:
+            mean, invstd = done["mean"], done["invstd"]   # written by the producing convolution's last workgroup
         else:
-            nrows = query("dj_reduce_rows", rows)
-            partial, conv_bias = plan.empty(nrows, 2, c), None
-            plan.emit(lambda: call("dj_colstats_partial", z, rows, c, ld, partial))
-        plan.emit(lambda: call("dj_bn_train_finalize", partial, nrows, rows, conv_bias, gamma, beta, self.epsilon,
-                               self.momentum, mm, mv, scale, shift, mean, invstd, c))
+            mean, invstd = plan.empty(c), plan.empty(c)
+            if x.conv_stats is not None:
+                partial, nrows, conv_bias = x.conv_stats
+            else:
+                nrows = query("dj_reduce_rows", rows)
+                partial, conv_bias = plan.empty(nrows, 2, c), None
+                plan.emit(lambda: call("dj_colstats_partial", z, rows, c, ld, partial))
+            plan.emit(lambda: call("dj_bn_train_finalize", partial, nrows, rows, conv_bias, gamma, beta, self.epsilon,
+                                   self.momentum, mm, mv, scale, shift, mean, invstd, c))
 
         def build_backward():
             src = out.relu_child if out.relu_child is not None else out

@@ -263,8 +263,13 @@ class Model(object):
         if training:
             plan.build_backward()
         if os.environ.get("DJ_AUTOTUNE", "1") != "0":
-            plan.autotune(reps=int(os.environ.get("DJ_AUTOTUNE_REPS", "2")),
-                          verbose=os.environ.get("DJ_AUTOTUNE_VERBOSE", "0") == "1")
+            # timing an untuned geometry runs its launch, and a conv that finalizes its BatchNormalization advances
+            # that layer's moving statistics: put the non-trainable state back afterwards
+            state = self.flat_all[self._store["n_train"]:]
+            saved = state.clone()
+            if plan.autotune(reps=int(os.environ.get("DJ_AUTOTUNE_REPS", "2")),
+                             verbose=os.environ.get("DJ_AUTOTUNE_VERBOSE", "0") == "1"):
+                state.copy_(saved)
             if os.environ.get("DJ_TUNE_SAVE"):
                 from ..engine import save_tune_db
                 save_tune_db(os.environ["DJ_TUNE_SAVE"])

@@ -107,6 +107,31 @@ def conv2d_fwd_addrelu(desc, x, w, bias, y, pro_scale, pro_shift, res, res_scale
     return y
 
 
+BN_ACC_REPLICAS = 16   # DJ_BN_ACC_REPLICAS of include/dj_hip.h
+
+
+def make_bn_train(acc, ticket, gamma, beta, moving_mean, moving_var, scale, shift, save_mean, save_invstd, eps, momentum):
+    """dj_bn_train descriptor (keeps the tensors alive through the returned object)."""
+    bn = _lib.BnTrain(ptr(acc), ptr(ticket), ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var), ptr(scale),
+                      ptr(shift), ptr(save_mean), ptr(save_invstd), float(eps), float(momentum))
+    bn._keep = (acc, ticket, gamma, beta, moving_mean, moving_var, scale, shift, save_mean, save_invstd)
+    return bn
+
+
+def conv2d_fwd_bn(desc, x, w, bias, y, bn, pro_scale=None, pro_shift=None, pro_relu=False, res=None, res_scale=None,
+                  res_shift=None, sum_out=None):
+    """Forward conv + the training-mode BatchNormalization statistics / coefficients of its output in one launch."""
+    import ctypes
+    d = _desc_for(desc, x, y)
+    assert w.is_contiguous() and tuple(w.shape) == (d.kernel_h, d.kernel_w, d.in_c, d.out_c)
+    check(_lib.load().dj_conv2d_nhwc_fwd_bn(d, ptr(x), ptr(w), ptr(bias), ptr(y), ptr(pro_scale), ptr(pro_shift),
+                                            int(pro_relu), ptr(res), _pixel_ld(res) if res is not None else 0,
+                                            ptr(res_scale), ptr(res_shift), ptr(sum_out),
+                                            _pixel_ld(sum_out) if sum_out is not None else 0, ctypes.byref(bn), _stream()),
+          "dj_conv2d_nhwc_fwd_bn")
+    return y
+
+
 def conv2d_dgrad(desc, dy, w, dx, bias=None, beta=False):
     d = _desc_for(desc, dx, dy)
     assert w.is_contiguous() and tuple(w.shape) == (d.kernel_h, d.kernel_w, d.in_c, d.out_c)

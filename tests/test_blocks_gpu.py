@@ -65,8 +65,12 @@ def _check(out, grads, ref_out, ref_grads, tol=1e-3):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("kind", ["conv_s1_k1", "conv_s2_k3", "identity_k2", "identity_k3"])
-def test_bottleneck_blocks(kind, cuda):
+@pytest.mark.parametrize("kind", ["conv_s1_k1", "conv_s2_k3", "identity_k2", "identity_k3", "identity_k3+bnfin"])
+def test_bottleneck_blocks(kind, cuda, monkeypatch):
+    if kind.endswith("+bnfin"):
+        # opt-in lowering: the convs finalize their BatchNormalization themselves (dj_conv2d_nhwc_fwd_bn)
+        monkeypatch.setenv("DJ_FUSE_BNFIN", "1")
+        kind = kind[:-len("+bnfin")]
     from jpeg_detection_resnet_ssd_amd.keras import backend as K
     from jpeg_detection_resnet_ssd_amd.keras.layers import BatchNormalization, Input
     from jpeg_detection_resnet_ssd_amd.keras.models import Model

@@ -249,3 +249,50 @@ def test_fwd_with_residual_add_prologue(geom, res_affine, cuda):
     _lib.check(lib.dj_conv2d_tune_set(4, desc, -1, 1), "tune_set")
     bad = K.make_conv_desc(b, h, w, ci, co, (3, 3), (1, 1), "same", (1, 1))
     assert not K.conv2d_fwd_addrelu_supported(bad)
+
+
+@pytest.mark.parametrize("geom", [(3, 19, 19, 96, 128, 3), (2, 38, 38, 64, 256, 1), (4, 10, 10, 256, 64, 1),
+                                  (8, 75, 75, 64, 64, 1)])   # the last one spreads over 5 accumulator replicas
+def test_fwd_with_fused_batchnorm_finalize(geom, cuda):
+    """dj_conv2d_nhwc_fwd_bn: scale / shift / saved and moving statistics written by the conv launch itself (fp64 atomics
+    + last-workgroup ticket) == conv statistics + dj_bn_train_finalize, for every tile variant, twice in a row (the
+    accumulators and the ticket must be left clean)."""
+    from jpeg_detection_resnet_ssd_amd import _lib
+    from jpeg_detection_resnet_ssd_amd import kernels as K
+    from jpeg_detection_resnet_ssd_amd.engine import call
+    lib = _lib.load()
+    b, h, w, ci, co, k = geom
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(b, h, w, ci, generator=g).to(cuda)
+    wt = (torch.randn(k, k, ci, co, generator=g) * (2.0 / (k * k * ci)) ** 0.5).to(cuda)
+    bias = torch.randn(co, generator=g).to(cuda)
+    gamma, beta = (torch.rand(co, generator=g) + 0.5).to(cuda), torch.randn(co, generator=g).to(cuda)
+    desc = K.make_conv_desc(b, h, w, ci, co, (k, k), (1, 1), "same", (1, 1))
+    rows = b * h * w
+    # reference: the two-launch path
+    y0 = torch.empty(b, h, w, co, device=cuda)
+    nr = K.conv2d_stats_rows(desc)
+    stats = torch.zeros(nr, 2, co, device=cuda)
+    mm0, mv0 = torch.zeros(co, device=cuda), torch.ones(co, device=cuda)
+    ref = [torch.empty(co, device=cuda) for _ in range(4)]
+    K.conv2d_fwd(desc, x, wt, bias, y0, None, None, False, False, stats)
+    call("dj_bn_train_finalize", stats, nr, rows, bias, gamma, beta, 1e-3, 0.99, mm0, mv0, *ref, co)
+    acc = torch.zeros(K.BN_ACC_REPLICAS * 2 * co, dtype=torch.float64, device=cuda)
+    ticket = torch.zeros(1, dtype=torch.int32, device=cuda)
+    for cfg in range(lib.dj_conv2d_tune_configs()):
+        _lib.check(lib.dj_conv2d_tune_set(4, desc, cfg, 1), "tune_set")
+        mm, mv = torch.zeros(co, device=cuda), torch.ones(co, device=cuda)
+        out = [torch.full((co,), float("nan"), device=cuda) for _ in range(4)]
+        bn = K.make_bn_train(acc, ticket, gamma, beta, mm, mv, out[0], out[1], out[2], out[3], 1e-3, 0.99)
+        y = torch.empty(b, h, w, co, device=cuda)
+        for rep in range(2):
+            K.conv2d_fwd_bn(desc, x, wt, bias, y, bn)
+        torch.cuda.synchronize()
+        assert (y - y0).abs().max() <= 1e-5 * y0.abs().max(), cfg   # other tile variant: other summation order
+        for got, want, name in zip(out, ref, ("scale", "shift", "mean", "invstd")):
+            assert (got - want).abs().max() <= 2e-6 * want.abs().max() + 1e-7, (cfg, name)
+        # two launches = two momentum updates of the moving statistics
+        mean, var_u = ref[2], None
+        assert (mm - (0.0 * 0.99 + ref[2] * 0.01) * (1 + 0.99)).abs().max() <= 1e-5 * ref[2].abs().max() + 1e-7, cfg
+        assert int(ticket.item()) == 0 and float(acc.abs().max()) == 0.0, cfg
+    _lib.check(lib.dj_conv2d_tune_set(4, desc, -1, 1), "tune_set")
