@@ -10,8 +10,9 @@ over ranks every step (hvd.DistributedOptimizer), rank 0's weights are broadcast
 
 MI355X specifics: all gradients live in ONE flat HBM buffer, so a bucket is a contiguous slice (no
 flatten/unflatten copies); buckets are formed in the order the backward pass finishes them and each
-all-reduce is issued from inside the plan's launch sequence right after the bucket's last wgrad, so
-RCCL (on its own stream) overlaps the rest of the backward.  xGMI is point-to-point (ring per link),
+all-reduce is issued from inside the plan's launch sequence right after the bucket's last wgrad (ordered
+after both of the plan's streams, without stalling the main one), so RCCL (on its own stream) overlaps the
+rest of the backward.  xGMI is point-to-point (ring per link),
 so buckets are large (default 32 MiB) to stay bandwidth- rather than latency-bound; the 1/world_size
 is folded into the SGD kernel instead of a separate scaling pass."""
 import os
@@ -119,7 +120,10 @@ class DataParallel(object):
         buckets = plan_buckets(ready, so, self.bucket_bytes)
         ex = self.exchange
         for idx, ranges in sorted(buckets, key=lambda b: -b[0]):
-            plan.bwd.insert(idx, (lambda r=ranges: (plan.join_side(), ex.launch(r))))
+            # issued from the side stream: the collective waits for the weight gradients there (and, through an event,
+            # for the main stream's bias / BatchNormalization gradients) while the main stream runs on -- a join here
+            # would stall the data-gradient chain once per bucket (27.54 vs 27.89 ms/step on a 1-rank communicator)
+            plan.bwd.insert(idx, (lambda r=ranges: plan.after_both_streams(lambda: ex.launch(r))))
         self._attached.add(id(plan))
         self.n_buckets = len(buckets)
 

@@ -242,6 +242,18 @@ class Plan(object):
             self._side_dirty = True
         return run
 
+    def after_both_streams(self, fn):
+        """Run `fn` with the side stream current, after everything issued so far on BOTH streams: what `fn` enqueues
+        (a collective: torch.distributed orders its communication stream after the current stream) then depends on the
+        weight gradients of the side stream and on the main stream's work without the main stream waiting for anybody."""
+        if self.side_stream is None or not self.side_enabled:
+            return fn()
+        ev = torch.cuda.Event()
+        ev.record()
+        self.side_stream.wait_event(ev)
+        with torch.cuda.stream(self.side_stream):
+            return fn()
+
     def join_side(self):
         """Make the main stream wait for the side-stream launches issued so far."""
         if self._side_dirty:
