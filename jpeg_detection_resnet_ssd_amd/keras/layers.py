@@ -279,7 +279,7 @@ class Conv2D(Layer):
             if os.environ.get("DJ_FUSE_BNFIN", "0") == "1":
                 # opt-in: the conv's last workgroup turns the column sums into the BatchNormalization coefficients itself
                 # (fp64 accumulators + a ticket, both left zero by that workgroup).  Saves the finalize launch but every
-                # workgroup pays a ticket round trip: 0.6 % SLOWER on the SSD300 step (DESIGN.md section 8), hence off
+                # workgroup pays a ticket round trip: 0.6 % SLOWER on the SSD300 step (DESIGN.md section 6), hence off
                 bnl, c = consumers[0], self.filters
                 fused_bn = dict(scale=plan.empty(c), shift=plan.empty(c), mean=plan.empty(c), invstd=plan.empty(c))
                 acc = torch.zeros(Kn.BN_ACC_REPLICAS * 2 * c, dtype=torch.float64, device=plan.device)
