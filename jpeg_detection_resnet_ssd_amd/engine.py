@@ -85,8 +85,10 @@ _DB = None    # "dir,geometry..." -> [cfg, splits, ms]: tile choices measured on
 
 
 def _tune_db():
-    """The in-tree table of measured tile choices (like a find-db: geometry -> kernel variant).  Geometries it does
-    not hold are timed at plan time; DJ_TUNE_DB=path selects another file, DJ_TUNE_DB=0 ignores it."""
+    """The in-tree table of measured tile choices (like a find-db: geometry -> kernel variant): [cfg, splits, ms alone]
+    per geometry, plus a trailing 1 where tools/tune_in_step.py replaced the fastest-alone choice by the one that makes
+    the whole training step fastest.  Geometries it does not hold are timed at plan time; DJ_TUNE_DB=path selects
+    another file, DJ_TUNE_DB=0 ignores it."""
     global _DB
     if _DB is None:
         _DB = {}
@@ -103,7 +105,10 @@ def save_tune_db(path=None):
     import json
     entries = dict(_tune_db())
     for key, (ms, cfg, sp) in _TUNED.items():
-        entries[",".join(str(int(v)) for v in key)] = [int(cfg), int(sp), round(float(ms), 5)]
+        name = ",".join(str(int(v)) for v in key)
+        if len(entries.get(name, ())) > 3:
+            continue     # an in-step choice (4th element): keep it as it is
+        entries[name] = [int(cfg), int(sp), round(float(ms), 5)]
     path = path or _TUNE_DB
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, "w") as f:
@@ -277,7 +282,9 @@ class Plan(object):
             known = _tune_db().get(",".join(str(int(v)) for v in key))
             if known is not None and known[0] < ncfg:
                 sp = int(known[1])
-                if (direction & 3) == 2 and self.side_stream is not None:
+                if len(known) > 3 and known[3]:
+                    pass    # chosen inside the training step (tools/tune_in_step.py): variant and split factor as they are
+                elif (direction & 3) == 2 and self.side_stream is not None:
                     # the table holds the split-K factor that is fastest for the weight-gradient GEMM ALONE; beside the
                     # data-gradient chain half as many workgroups (and half the atomic traffic) disturb the HBM-bound
                     # kernels of that chain less: +0.7 % on the step (1134 vs 1126 img/s, same box)
