@@ -51,8 +51,9 @@ for direction, desc, _ in plan.conv_calls:
 cur = {}
 for key, (direction, desc, count) in geoms.items():
     ms, cfg, sp = engine._TUNED[key]
-    if (direction & 3) == 2 and plan.side_stream is not None:
-        sp = max(1, (sp + 1) // 2)
+    known = engine._tune_db().get(",".join(str(int(v)) for v in key), ())
+    if (direction & 3) == 2 and plan.side_stream is not None and not (len(known) > 3 and known[3]):
+        sp = max(1, (sp + 1) // 2)      # what Plan.autotune registered for a fastest-alone entry
     cur[key] = (cfg, sp, ms * count)
 order = sorted(geoms, key=lambda k: -cur[k][2])[:max_geoms]
 
