@@ -4,7 +4,9 @@ variant beside other work need not be the same.  This tool takes the plan of one
 the most expensive down, tries every variant (and, for weight gradients, neighbouring split-K factors) IN the step and
 keeps a change only when the whole step gets faster, re-measured A/B/A against the current choice.
 
-    python tools/tune_in_step.py deconv 32 gpurun_out/step_tune.json [max_geometries] [seconds]
+    python tools/tune_in_step.py deconv 32 gpurun_out/step_tune.json [max_geometries] [seconds] [protect_archi]
+
+`protect_archi`: geometries that also occur in that workload's plan are left alone (their entry was chosen there).
 
 Output: {"<dir>,<geometry>": [cfg, splits, step_gain_ms, 1]}; the trailing 1 marks "splits measured beside the other
 stream: use as is" for engine.Plan.autotune."""
@@ -23,6 +25,7 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 out_path = sys.argv[3] if len(sys.argv) > 3 else "gpurun_out/step_tune.json"
 max_geoms = int(sys.argv[4]) if len(sys.argv) > 4 else 40
 budget_s = float(sys.argv[5]) if len(sys.argv) > 5 else 420.0
+protect = sys.argv[6] if len(sys.argv) > 6 else None
 
 lib = _lib.load()
 ncfg = lib.dj_conv2d_tune_configs()
@@ -55,7 +58,13 @@ for key, (direction, desc, count) in geoms.items():
     if (direction & 3) == 2 and plan.side_stream is not None and not (len(known) > 3 and known[3]):
         sp = max(1, (sp + 1) // 2)      # what Plan.autotune registered for a fastest-alone entry
     cur[key] = (cfg, sp, ms * count)
-order = sorted(geoms, key=lambda k: -cur[k][2])[:max_geoms]
+protected = set()
+if protect:
+    other, _ = workloads.build_ssd(protect)
+    for direction, desc, _ in other._plan(B, True, True).conv_calls:
+        protected.add((direction,) + tuple(getattr(desc, n) for n in names))
+    del other
+order = [k for k in sorted(geoms, key=lambda k: -cur[k][2]) if k not in protected][:max_geoms]
 
 
 def apply(key, cfg, sp):
