@@ -266,10 +266,11 @@ class Plan(object):
             torch.cuda.current_stream().wait_event(self._join_event)
             self._side_dirty = False
 
-    def autotune(self, reps=2, verbose=False):
+    def autotune(self, reps=2, verbose=False, measure=True):
         """Time every distinct conv geometry of this plan under each tile configuration / split-K factor on the
         plan's own buffers and register the fastest with the launcher (dj_conv2d_tune_set).  Results only depend on
-        the geometry, so they are shared by all plans of the process."""
+        the geometry, so they are shared by all plans of the process.  measure=False: only apply what the in-tree table
+        holds; other geometries keep the launcher's default variant (deterministic, nothing is run)."""
         import ctypes
         lib = _lib.load()
         ncfg = lib.dj_conv2d_tune_configs()
@@ -291,6 +292,8 @@ class Plan(object):
                     sp = max(1, (sp + 1) // 2)
                 check(lib.dj_conv2d_tune_set(direction, desc, int(known[0]), sp), "tune_set")
                 _TUNED[key] = (float(known[2]), int(known[0]), int(known[1]))
+                continue
+            if not measure:
                 continue
             c0, s0 = ctypes.c_int(0), ctypes.c_int(1)
             check(lib.dj_conv2d_default_config(direction, desc, ctypes.byref(c0), ctypes.byref(s0)), "default_config")

@@ -268,7 +268,8 @@ class Model(object):
             state = self.flat_all[self._store["n_train"]:]
             saved = state.clone()
             if plan.autotune(reps=int(os.environ.get("DJ_AUTOTUNE_REPS", "2")),
-                             verbose=os.environ.get("DJ_AUTOTUNE_VERBOSE", "0") == "1"):
+                             verbose=os.environ.get("DJ_AUTOTUNE_VERBOSE", "0") == "1",
+                             measure=os.environ.get("DJ_AUTOTUNE", "1") != "table"):
                 state.copy_(saved)
             if os.environ.get("DJ_TUNE_SAVE"):
                 from ..engine import save_tune_db

@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Geometries the in-tree tuning table does not hold (the small batches of the parity tests) would be TIMED at plan
+    # time, and which tile variant wins a close race differs from run to run -- with it the summation order and, in the
+    # ill-conditioned full-graph gradient checks, the last digits the tolerances were measured with.  "table": apply the
+    # table where it has an entry (the full-size tests), the launcher's deterministic default variant elsewhere (every
+    # variant has its own test in test_conv_gpu.py).  DJ_AUTOTUNE=1 in the environment restores the timing.
+    os.environ.setdefault("DJ_AUTOTUNE", "table")
 
 
 def pytest_sessionstart(session):
