@@ -191,7 +191,7 @@ def main(json_out=None):
             "note": "whole-step algorithmic conv FLOPs (SURVEY 8(d) table) / step time, per GPU"}
     traffic_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_igemm_traffic.json")
     if os.path.exists(traffic_file) and args.archi == "deconv" and args.batch == 32:
-        # offline rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_e_hbm_traffic.md), bytes per launch
+        # offline rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_f_hbm_traffic_pmc.md), bytes per launch
         with open(traffic_file) as f:
             roof["traffic"] = json.load(f)["bytes_per_launch"]
     if world == 1:
