@@ -562,7 +562,13 @@ class _Prefetcher(object):
     def close(self):
         """Stop the thread and wait for it (a generator must not be resumed by two threads); batches it had already
         produced are dropped, as Keras' enqueuer does on stop()."""
+        import queue
         self.stop.set()
+        try:                      # a producer blocked on the full queue would only notice `stop` after its put timeout
+            while True:
+                self.q.get_nowait()
+        except queue.Empty:
+            pass
         self.thread.join()
 
 

@@ -3,12 +3,14 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from jpeg_detection_resnet_ssd_amd import kernels as K, _lib
-b, h, w, co = 32, 19, 19, 256
 mode = sys.argv[1] if len(sys.argv) > 1 else "fwd"
 cfg = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+b = 32
+h = w = int(sys.argv[3]) if len(sys.argv) > 3 else 19
+co = int(sys.argv[4]) if len(sys.argv) > 4 else 256
 dev = torch.device("cuda:0")
 lib = _lib.load()
-for ci in (32, 64, 128, 256, 512, 1024, 2048, 4096):
+for ci in (32, 64, 128, 256, 512, 1024, 2048):
     desc = K.make_conv_desc(b, h, w, ci, co, (1, 1), (1, 1), "valid", (1, 1))
     x = torch.randn(b, h, w, ci, device=dev); wt = torch.randn(1, 1, ci, co, device=dev) * 0.05
     y = torch.empty(b, h, w, co, device=dev); dy = torch.randn_like(y); dx = torch.empty_like(x)
