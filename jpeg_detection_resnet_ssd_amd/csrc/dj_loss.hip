@@ -13,40 +13,52 @@ static inline int ew_blocks(long total) {
 }
 
 // ---------------------------------------------------------------------------------
-// softmax over the last axis: one wave per row
+// softmax over the last axis: one row per group of G = 8 / 16 / 32 / 64 lanes (the 21-class rows of the SSD head: two rows per
+// wave).  The xor butterfly of a group is the tail of the 64-lane butterfly, whose first steps would only add the
+// identity held by the lanes beyond C -- same bits for any G >= C.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dj_softmax_fwd_kernel(const float* x, float* y, long rows, int C) {
-  long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  int lane = threadIdx.x & 63;
-  if (row >= rows) return;
-  const float* xr = x + row * C;
+static inline int softmax_group(int C) {
+  int g = 8;
+  while (g < 64 && g < C) g <<= 1;
+  return g;
+}
+
+__global__ __launch_bounds__(256) void dj_softmax_fwd_kernel(const float* x, float* y, long rows, int C, int G) {
+  const int per_wave = 64 / G;
+  const int lane = threadIdx.x & 63, sub = lane / G, l = lane - sub * G;
+  long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * per_wave + sub;
+  const bool live = row < rows;
+  const float* xr = x + (live ? row : 0) * C;
   float m = -INFINITY;
-  for (int c = lane; c < C; c += 64) m = fmaxf(m, xr[c]);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (live)
+    for (int c = l; c < C; c += G) m = fmaxf(m, xr[c]);
+  for (int o = G >> 1; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   float s = 0.f;
-  for (int c = lane; c < C; c += 64) s += expf(xr[c] - m);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (live)
+    for (int c = l; c < C; c += G) s += expf(xr[c] - m);
+  for (int o = G >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (!live) return;
   float inv = 1.f / s;
   float* yr = y + row * C;
-  for (int c = lane; c < C; c += 64) yr[c] = expf(xr[c] - m) * inv;
+  for (int c = l; c < C; c += G) yr[c] = expf(xr[c] - m) * inv;
 }
 
 // dx (+)= p * (dp - sum(dp*p))
 __global__ __launch_bounds__(256) void dj_softmax_bwd_kernel(const float* p, const float* dp, long ld_dp, float* dx,
-                                                              long rows, int C, int beta) {
-  long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  int lane = threadIdx.x & 63;
-  if (row >= rows) return;
-  const float* pr = p + row * C;
-  const float* gr = dp + row * ld_dp;
+                                                              long rows, int C, int beta, int G) {
+  const int per_wave = 64 / G;
+  const int lane = threadIdx.x & 63, sub = lane / G, l = lane - sub * G;
+  long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * per_wave + sub;
+  const bool live = row < rows;
+  const float* pr = p + (live ? row : 0) * C;
+  const float* gr = dp + (live ? row : 0) * ld_dp;
   float dot = 0.f;
-  for (int c = lane; c < C; c += 64) dot += pr[c] * gr[c];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+  if (live)
+    for (int c = l; c < C; c += G) dot += pr[c] * gr[c];
+  for (int o = G >> 1; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+  if (!live) return;
   float* dr = dx + row * C;
-  for (int c = lane; c < C; c += 64) {
+  for (int c = l; c < C; c += G) {
     float v = pr[c] * (gr[c] - dot);
     dr[c] = beta ? dr[c] + v : v;
   }
@@ -54,8 +66,9 @@ __global__ __launch_bounds__(256) void dj_softmax_bwd_kernel(const float* p, con
 
 extern "C" int dj_softmax_fwd(const float* x, float* y, long rows, int C, void* stream) {
   DJ_CHECK_ARG(x && y && rows > 0 && C > 0, "softmax_fwd: bad arguments");
-  hipLaunchKernelGGL(dj_softmax_fwd_kernel, dim3((unsigned)dj_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, y,
-                     rows, C);
+  const int G = softmax_group(C);
+  hipLaunchKernelGGL(dj_softmax_fwd_kernel, dim3((unsigned)dj_cdiv(rows, 4 * (64 / G))), dim3(256), 0, (hipStream_t)stream,
+                     x, y, rows, C, G);
   DJ_CHECK_LAUNCH("dj_softmax_fwd");
   return DJ_OK;
 }
@@ -63,8 +76,9 @@ extern "C" int dj_softmax_fwd(const float* x, float* y, long rows, int C, void* 
 extern "C" int dj_softmax_bwd(const float* p, const float* dp, long ld_dp, float* dx, long rows, int C, int beta,
                               void* stream) {
   DJ_CHECK_ARG(p && dp && dx && rows > 0 && C > 0 && ld_dp >= C, "softmax_bwd: bad arguments");
-  hipLaunchKernelGGL(dj_softmax_bwd_kernel, dim3((unsigned)dj_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, p, dp,
-                     ld_dp, dx, rows, C, beta);
+  const int G = softmax_group(C);
+  hipLaunchKernelGGL(dj_softmax_bwd_kernel, dim3((unsigned)dj_cdiv(rows, 4 * (64 / G))), dim3(256), 0, (hipStream_t)stream,
+                     p, dp, ld_dp, dx, rows, C, beta, G);
   DJ_CHECK_LAUNCH("dj_softmax_bwd");
   return DJ_OK;
 }
@@ -310,31 +324,38 @@ __global__ __launch_bounds__(256) void dj_ssd_loss_finalize_kernel(const float* 
   }
 }
 
-// d y_pred: classes -w*y_c/p_c [p_c > 1e-15], offsets -pos*alpha*f'(t-p), rest 0; all / max(1,n_pos) * upstream
+// d y_pred: classes -w*y_c/p_c [p_c > 1e-15], offsets -pos*alpha*f'(t-p), rest 0; all / max(1,n_pos) * upstream.
+// One thread per ELEMENT of the (box, n_cls + 12) tensors: consecutive lanes touch consecutive floats (a thread per box
+// strides by 132 B: 141 us against 30 us for the 6716-box, batch-32 head), and the rows of boxes that were neither
+// matched nor mined -- 99 % of them -- are written as zeros without reading y_true / y_pred.
 __global__ __launch_bounds__(256) void dj_ssd_loss_bwd_kernel(const float* y_true, const float* y_pred,
                                                                const float* pos, const float* keep, const float* out,
                                                                long nbox, int n_cls, float alpha, float upstream,
                                                                float* d_pred) {
   const int W = n_cls + 12;
-  float npos = out[1];
-  float inv = upstream / fmaxf(npos, 1.f);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nbox; i += (long)gridDim.x * blockDim.x) {
-    const float* t = y_true + i * W;
-    const float* p = y_pred + i * W;
-    float* d = d_pred + i * W;
-    float ps = pos[i];
-    float w = (ps + keep[i]) * inv;
-    for (int c = 0; c < n_cls; ++c) {
-      float pc = p[c];
-      d[c] = (w != 0.f && pc > 1e-15f) ? -w * t[c] / pc : 0.f;
+  const float npos = out[1];
+  const float inv = upstream / fmaxf(npos, 1.f);
+  const long total = nbox * W;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long i = e / W;
+    const int c = (int)(e - i * W);
+    const float ps = pos[i];
+    float v = 0.f;
+    if (c < n_cls) {
+      const float w = (ps + keep[i]) * inv;
+      if (w != 0.f) {
+        const float pc = y_pred[e];
+        if (pc > 1e-15f) v = -w * y_true[e] / pc;
+      }
+    } else if (c < n_cls + 4) {
+      const float wl = ps * alpha * inv;
+      if (wl != 0.f) {
+        const float df = y_true[e] - y_pred[e];
+        const float g = (fabsf(df) < 1.f) ? df : ((df > 0.f) ? 1.f : (df < 0.f ? -1.f : 0.f));
+        v = -wl * g;
+      }
     }
-    float wl = ps * alpha * inv;
-    for (int j = 0; j < 4; ++j) {
-      float df = t[n_cls + j] - p[n_cls + j];
-      float g = (fabsf(df) < 1.f) ? df : ((df > 0.f) ? 1.f : (df < 0.f ? -1.f : 0.f));
-      d[n_cls + j] = -wl * g;
-    }
-    for (int j = 4; j < 12; ++j) d[n_cls + j] = 0.f;
+    d_pred[e] = v;
   }
 }
 
@@ -392,7 +413,7 @@ extern "C" int dj_ssd_loss_bwd(const float* y_true, const float* y_pred, long nb
   DJ_CHECK_ARG(y_true && y_pred && workspace && out5 && d_pred && nbox > 0 && n_cls > 1, "ssd_loss_bwd: bad arguments");
   const float* pos = workspace + 2 * nbox;
   const float* keep = workspace + 4 * nbox;
-  hipLaunchKernelGGL(dj_ssd_loss_bwd_kernel, dim3(ew_blocks(nbox)), dim3(256), 0, (hipStream_t)stream, y_true, y_pred,
+  hipLaunchKernelGGL(dj_ssd_loss_bwd_kernel, dim3(ew_blocks(nbox * (n_cls + 12))), dim3(256), 0, (hipStream_t)stream, y_true, y_pred,
                      pos, keep, out5, nbox, n_cls, alpha, upstream, d_pred);
   DJ_CHECK_LAUNCH("dj_ssd_loss_bwd");
   return DJ_OK;
