@@ -815,6 +815,86 @@ __global__ __launch_bounds__(256) void dj_maxpool2d_bwd_kernel(const float* x, c
   }
 }
 
+// Four channels per thread (C % 4 == 0, 16-byte aligned tensors): one float4 per tap, the four tap codes as one 32-bit
+// store, and the index arithmetic (runtime divisions) paid once per four elements.  Same comparisons in the same window
+// order as the scalar kernels, channel by channel.
+__global__ __launch_bounds__(256) void dj_maxpool2d_fwd4_kernel(const float* x, float* y, unsigned char* argmax,
+                                                                 PoolGeom g) {
+  const int cv = g.C / 4;
+  const long total = (long)g.B * g.OH * g.OW * cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * 4;
+    const int p = (int)(i / cv);
+    const int ow = p % g.OW;
+    const int q = p / g.OW;
+    const int oh = q % g.OH;
+    const int b = q / g.OH;
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    unsigned code[4] = {255u, 255u, 255u, 255u};
+    for (int ki = 0; ki < g.kh; ++ki)
+      for (int kj = 0; kj < g.kw; ++kj) {
+        const int hh = oh * g.sh + ki - g.pt, ww = ow * g.sw + kj - g.pl;
+        const bool in = (unsigned)hh < (unsigned)g.H && (unsigned)ww < (unsigned)g.W;
+        if (!in && !g.pad_zero) continue;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (in) v = VecIO<4>::ld(x + ((long)(b * g.H + hh) * g.W + ww) * g.C + c);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        const unsigned tap = in ? (unsigned)(ki * g.kw + kj) : 255u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (vv[j] > m[j]) {
+            m[j] = vv[j];
+            code[j] = tap;
+          }
+      }
+    const long o = (long)p * g.C + c;
+    VecIO<4>::st(y + o, f32x4{m[0], m[1], m[2], m[3]});
+    if (argmax)
+      *reinterpret_cast<unsigned*>(argmax + o) = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
+  }
+}
+
+__global__ __launch_bounds__(256) void dj_maxpool2d_bwd4_kernel(const unsigned char* argmax, const float* dy, float* dx,
+                                                                 PoolGeom g, int beta) {
+  const int cv = g.C / 4;
+  const long total = (long)g.B * g.H * g.W * cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * 4;
+    const int p = (int)(i / cv);
+    const int w = p % g.W;
+    const int q = p / g.W;
+    const int h = q % g.H;
+    const int b = q / g.H;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int oh_lo = (h + g.pt - g.kh + g.sh) / g.sh;
+    if (h + g.pt - g.kh + 1 <= 0) oh_lo = 0;
+    int oh_hi = (h + g.pt) / g.sh;
+    int ow_lo = (w + g.pl - g.kw + g.sw) / g.sw;
+    if (w + g.pl - g.kw + 1 <= 0) ow_lo = 0;
+    int ow_hi = (w + g.pl) / g.sw;
+    if (oh_hi >= g.OH) oh_hi = g.OH - 1;
+    if (ow_hi >= g.OW) ow_hi = g.OW - 1;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh)
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        const long o = ((long)(b * g.OH + oh) * g.OW + ow) * g.C + c;
+        const unsigned codes = *reinterpret_cast<const unsigned*>(argmax + o);
+        const unsigned mine = (unsigned)((h - (oh * g.sh - g.pt)) * g.kw + (w - (ow * g.sw - g.pl)));
+        if (((codes & 255u) != mine) && (((codes >> 8) & 255u) != mine) && (((codes >> 16) & 255u) != mine) &&
+            ((codes >> 24) != mine))
+          continue;
+        const f32x4 d = VecIO<4>::ld(dy + o);
+        if ((codes & 255u) == mine) acc[0] += d.x;
+        if (((codes >> 8) & 255u) == mine) acc[1] += d.y;
+        if (((codes >> 16) & 255u) == mine) acc[2] += d.z;
+        if ((codes >> 24) == mine) acc[3] += d.w;
+      }
+    float* dst = dx + (long)p * g.C + c;
+    f32x4 r = {acc[0], acc[1], acc[2], acc[3]};
+    if (beta) r = r + VecIO<4>::ld(dst);
+    VecIO<4>::st(dst, r);
+  }
+}
+
 static int pool_geom(PoolGeom* g, int B, int H, int W, int C, int OH, int OW, int kh, int kw, int sh, int sw, int pt,
                      int pl, int pad_zero) {
   DJ_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 && pt >= 0 &&
@@ -831,8 +911,13 @@ extern "C" int dj_maxpool2d_fwd(const float* x, float* y, int B, int H, int W, i
   DJ_CHECK_ARG(!argmax || kh * kw < 255, "maxpool fwd: window too large for the saved arg-max encoding");
   PoolGeom g;
   if (int rc = pool_geom(&g, B, H, W, C, OH, OW, kh, kw, sh, sw, pt, pl, pad_zero)) return rc;
-  hipLaunchKernelGGL(dj_maxpool2d_fwd_kernel, dim3(ew_blocks((long)B * OH * OW * C)), dim3(256), 0, (hipStream_t)stream,
-                     x, y, argmax, g);
+  const bool small = (long)B * H * W < (1L << 31) / 4 && (long)B * OH * OW < (1L << 31) / 4;   // 32-bit pixel indices
+  if (C % 4 == 0 && small && al16(x) && al16(y) && (((uintptr_t)argmax) & 3) == 0)
+    hipLaunchKernelGGL(dj_maxpool2d_fwd4_kernel, dim3(ew_blocks((long)B * OH * OW * (C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, x, y, argmax, g);
+  else
+    hipLaunchKernelGGL(dj_maxpool2d_fwd_kernel, dim3(ew_blocks((long)B * OH * OW * C)), dim3(256), 0, (hipStream_t)stream,
+                       x, y, argmax, g);
   DJ_CHECK_LAUNCH("dj_maxpool2d_fwd");
   return DJ_OK;
 }
@@ -843,7 +928,11 @@ extern "C" int dj_maxpool2d_bwd(const float* x, const float* dy, float* dx, int 
   DJ_CHECK_ARG((x || argmax) && dy && dx, "maxpool bwd: null tensor");
   PoolGeom g;
   if (int rc = pool_geom(&g, B, H, W, C, OH, OW, kh, kw, sh, sw, pt, pl, pad_zero)) return rc;
-  if (argmax)
+  const bool small = (long)B * H * W < (1L << 31) / 4 && (long)B * OH * OW < (1L << 31) / 4;
+  if (argmax && C % 4 == 0 && small && al16(dy) && al16(dx) && (((uintptr_t)argmax) & 3) == 0)
+    hipLaunchKernelGGL(dj_maxpool2d_bwd4_kernel, dim3(ew_blocks((long)B * H * W * (C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, argmax, dy, dx, g, beta);
+  else if (argmax)
     hipLaunchKernelGGL(dj_maxpool2d_bwd_kernel<true>, dim3(ew_blocks((long)B * H * W * C)), dim3(256), 0,
                        (hipStream_t)stream, x, argmax, dy, dx, g, beta);
   else

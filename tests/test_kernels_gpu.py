@@ -136,18 +136,18 @@ def test_l2norm(shape, cuda, E):
 
 
 @pytest.mark.parametrize("saved", [False, True])
-@pytest.mark.parametrize("hw", [5, 10])
-def test_maxpool(hw, saved, cuda, E):
+@pytest.mark.parametrize("hw,ch", [(5, 256), (10, 256), (7, 30)])   # 30 channels: the scalar kernels (C % 4 != 0)
+def test_maxpool(hw, ch, saved, cuda, E):
     g = torch.Generator().manual_seed(9)
-    x = torch.relu(torch.randn(3, hw, hw, 256, generator=g))     # exact ties (zeros): first maximum must win
-    dy = torch.randn(3, hw, hw, 256, generator=g)
+    x = torch.relu(torch.randn(3, hw, hw, ch, generator=g))     # exact ties (zeros): first maximum must win
+    dy = torch.randn(3, hw, hw, ch, generator=g)
     xr = x.double().requires_grad_(True)
     yr = ko.max_pool_3x3_s1_same(xr)
     yr.backward(dy.double())
     y, dx = torch.empty(x.shape, device=cuda), torch.empty(x.shape, device=cuda)
     am = torch.empty(x.numel(), dtype=torch.uint8, device=cuda) if saved else None
-    E.call("dj_maxpool2d_fwd", x.to(cuda), y, 3, hw, hw, 256, hw, hw, 3, 3, 1, 1, 1, 1, 0, am)
-    E.call("dj_maxpool2d_bwd", None if saved else x.to(cuda), dy.to(cuda), dx, 3, hw, hw, 256, hw, hw, 3, 3, 1, 1, 1, 1,
+    E.call("dj_maxpool2d_fwd", x.to(cuda), y, 3, hw, hw, ch, hw, hw, 3, 3, 1, 1, 1, 1, 0, am)
+    E.call("dj_maxpool2d_bwd", None if saved else x.to(cuda), dy.to(cuda), dx, 3, hw, hw, ch, hw, hw, 3, 3, 1, 1, 1, 1,
            0, 0, am)
     torch.cuda.synchronize()
     assert torch.equal(y.cpu().double(), yr.detach())
