@@ -147,6 +147,16 @@ int dj_colreduce_finalize(const float* partial, int nrows, int C, int which, flo
 /* out[c] (+)= sum over rows of x[r][c] in one launch -- bias gradients (BiasAddGrad) of the SSD head convs, whose
  * gradient tensors have at most a few thousand rows. */
 int dj_colsum_direct(const float* x, long rows, int C, int ld, float* out, int beta, void* stream);
+/* dj_colsum_direct for up to DJ_COLSUM_PARTS tensors in one launch (the bias gradients of the SSD head convolutions,
+ * deferred to the end of the backward pass). */
+#define DJ_COLSUM_PARTS 32
+typedef struct dj_colsum_part {
+  const float* x;
+  float* out;
+  long rows;
+  int C, ld, beta;
+} dj_colsum_part;
+int dj_colsum_multi(const dj_colsum_part* parts, int n_parts, void* stream);
 
 /* ---- keras.layers.BatchNormalization(axis=3) (Keras 2.2.4 defaults eps 1e-3, momentum 0.99) ----
  * Training forward = statistics (conv epilogue `stats` or dj_colstats_partial) -> dj_bn_train_finalize

@@ -25,6 +25,10 @@ class CopyPart(Structure):   # dj_copy_part
                 ("cols", c_long), ("beta", c_int)]
 
 
+class ColsumPart(Structure):   # dj_colsum_part
+    _fields_ = [("x", c_void_p), ("out", c_void_p), ("rows", c_long), ("C", c_int), ("ld", c_int), ("beta", c_int)]
+
+
 class ConvDesc(Structure):
     """Mirror of `dj_conv2d_desc` (include/dj_hip.h)."""
     _fields_ = [(n, c_int) for n in (
@@ -68,6 +72,7 @@ SIGNATURES = {
     "dj_conv2d_nhwc_fwd_addrelu": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, FP, FP, c_int, FP, FP, FP, c_int, c_int, FP,
                                            c_void_p]),
     "dj_colsum_direct": (c_int, [FP, c_long, c_int, c_int, FP, c_int, c_void_p]),
+    "dj_colsum_multi": (c_int, [POINTER(ColsumPart), c_int, c_void_p]),
     "dj_copy2d_multi": (c_int, [POINTER(CopyPart), c_int, c_void_p]),
     "dj_conv2d_nhwc_fwd_bn": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, FP, c_int, FP, c_int, FP, FP, FP, c_int,
                                       POINTER(BnTrain), c_void_p]),

@@ -256,8 +256,7 @@ extern "C" int dj_colreduce_finalize(const float* partial, int nrows, int C, int
 
 // out[c] (+)= sum_r x[r][c] in ONE launch (1024 threads = 16 columns x 64 row lanes, double accumulation): the bias
 // gradients of the SSD head convolutions have at most a few thousand rows, where two launches cost more than the sum
-__global__ __launch_bounds__(DJ_FIN_THREADS) void dj_colsum_direct_kernel(const float* x, long rows, int C, int ld, float* out,
-                                                                          int beta) {
+__device__ __forceinline__ void dj_colsum_direct_body(const float* x, long rows, int C, int ld, float* out, int beta) {
   __shared__ double red[DJ_FIN_LANES][DJ_FIN_CH + 1];
   const int tx = threadIdx.x & (DJ_FIN_CH - 1), ty = threadIdx.x / DJ_FIN_CH;
   const int c = blockIdx.x * DJ_FIN_CH + tx;
@@ -288,6 +287,38 @@ __global__ __launch_bounds__(DJ_FIN_THREADS) void dj_colsum_direct_kernel(const 
     float v = (float)a;
     out[c] = beta ? out[c] + v : v;
   }
+}
+
+__global__ __launch_bounds__(DJ_FIN_THREADS) void dj_colsum_direct_kernel(const float* x, long rows, int C, int ld, float* out,
+                                                                          int beta) {
+  dj_colsum_direct_body(x, rows, C, ld, out, beta);
+}
+
+// the same for up to DJ_COLSUM_PARTS tensors in one launch (blockIdx.y = tensor): the twenty-odd bias gradients of the SSD
+// head and extra-feature convolutions, each a 5 us launch on the backward chain, become one launch at its end
+struct DjColsumParts {
+  dj_colsum_part part[DJ_COLSUM_PARTS];
+};
+__global__ __launch_bounds__(DJ_FIN_THREADS) void dj_colsum_multi_kernel(const DjColsumParts ps) {
+  const dj_colsum_part& p = ps.part[blockIdx.y];
+  if ((int)blockIdx.x * DJ_FIN_CH >= p.C) return;   // uniform per workgroup: no barrier is skipped by part of it
+  dj_colsum_direct_body(p.x, p.rows, p.C, p.ld, p.out, p.beta);
+}
+
+extern "C" int dj_colsum_multi(const dj_colsum_part* parts, int n_parts, void* stream) {
+  DJ_CHECK_ARG(parts && n_parts >= 1 && n_parts <= DJ_COLSUM_PARTS, "colsum_multi: 1..%d parts", DJ_COLSUM_PARTS);
+  DjColsumParts ps;
+  int most = 0;
+  for (int i = 0; i < n_parts; ++i) {
+    const dj_colsum_part& p = parts[i];
+    DJ_CHECK_ARG(p.x && p.out && p.rows > 0 && p.C > 0 && p.ld >= p.C, "colsum_multi: bad part %d", i);
+    ps.part[i] = p;
+    if (p.C > most) most = p.C;
+  }
+  hipLaunchKernelGGL(dj_colsum_multi_kernel, dim3(dj_cdiv(most, DJ_FIN_CH), n_parts), dim3(DJ_FIN_THREADS), 0,
+                     (hipStream_t)stream, ps);
+  DJ_CHECK_LAUNCH("dj_colsum_multi");
+  return DJ_OK;
 }
 
 extern "C" int dj_colsum_direct(const float* x, long rows, int C, int ld, float* out, int beta, void* stream) {

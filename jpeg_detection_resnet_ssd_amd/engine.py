@@ -68,6 +68,26 @@ def copy2d_multi(parts):
     return run
 
 
+def colsum_multi(parts):
+    """parts: list of (x, rows, c, ld, out) -> a launcher issuing dj_colsum_multi (32 tensors per launch)."""
+    lib = _lib.load()
+    chunks = []
+    for i in range(0, len(parts), 32):
+        chunk = parts[i:i + 32]
+        arr = (_lib.ColsumPart * len(chunk))()
+        for k, (x, rows, c, ld, out) in enumerate(chunk):
+            arr[k] = _lib.ColsumPart(x.data_ptr(), out.data_ptr(), int(rows), int(c), int(ld), 0)
+        chunks.append((arr, len(chunk)))
+    keep = [(p[0], p[4]) for p in parts]
+
+    def run():
+        stream = torch.cuda.current_stream().cuda_stream
+        for arr, n in chunks:
+            check(lib.dj_colsum_multi(arr, n, stream), "dj_colsum_multi")
+    run._keep = keep
+    return run
+
+
 def tuned_splits(direction, desc):
     """Split-K factor the in-tree table registers for this geometry (None: not in the table)."""
     names = [n for n, _ in _lib.ConvDesc._fields_][:15]
@@ -170,6 +190,7 @@ class Plan(object):
         self.bytes_allocated = 0
         self.hooks_after_backward = []
         self.grad_ready = {}   # weight key -> index in self.bwd after which its gradient is final
+        self.deferred_colsums = []   # (dy, rows, c, ld, grad buffer, weight spec): see build_backward
         self.conv_calls = []   # (direction, ConvDesc, launch closure) of every implicit-GEMM call, for autotune()
         self.grads_cleared = False   # True: the first backward launch zeroes the model's whole flat gradient buffer
         # weight-gradient GEMMs only feed the optimizer, so they run on a second HIP stream and fill the CUs the
@@ -347,6 +368,12 @@ class Plan(object):
         for b in reversed(self._bwd_builders):
             b()
         self._bwd_builders = []
+        if self.deferred_colsums:
+            # short column sums (bias gradients) nobody reads before the optimizer: one launch for all of them
+            self.emit_bwd(colsum_multi([p[:5] for p in self.deferred_colsums]))
+            for p in self.deferred_colsums:
+                self.note_grad(p[5])
+            self.deferred_colsums = []
 
     # ---- gradients ------------------------------------------------------------
     def grad_of(self, v, zeroed=False):

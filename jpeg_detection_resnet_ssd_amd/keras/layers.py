@@ -212,8 +212,8 @@ def _bias_grad(plan, dy, spec):
     """dbias = column sum of dy (one launch for short tensors, two-stage otherwise)."""
     rows, c, ld = rows_of(dy)
     if rows <= 8192:
-        plan.emit_bwd(lambda: call("dj_colsum_direct", dy, rows, c, ld, spec.grad, 0))
-        plan.note_grad(spec)
+        # one dj_colsum_multi launch for all of these at the end of the backward pass (dy stays as it is until then)
+        plan.deferred_colsums.append((dy, rows, c, ld, spec.grad, spec))
         return
     nr = query("dj_reduce_rows", rows)
     partial = plan.empty(nr, 2, c)

@@ -288,3 +288,20 @@ def test_colsum_direct(rows, c, ld, cuda, E):
     E.call("dj_colsum_direct", x.to(cuda), rows, c, ld, out, 1)
     torch.cuda.synchronize()
     assert close(out.cpu(), 1.5 + x[:, :c].double().sum(0), rel=1e-6)
+
+
+def test_colsum_multi(cuda):
+    """dj_colsum_multi: 35 tensors of different shapes (two launches of <= 32 parts) == dj_colsum_direct one by one, bit
+    for bit (same kernel body)."""
+    from jpeg_detection_resnet_ssd_amd import engine
+    g = torch.Generator().manual_seed(4)
+    shapes = [(3200, 126, 126), (800, 24, 24), (37, 5, 9), (8192, 512, 512), (32, 84, 84), (288, 16, 16), (1, 3, 7)] * 5
+    xs = [torch.randn(r, ld, generator=g).to(cuda) for r, _, ld in shapes]
+    outs = [torch.empty(c, device=cuda) for _, c, _ in shapes]
+    refs = [torch.empty(c, device=cuda) for _, c, _ in shapes]
+    engine.colsum_multi([(x, r, c, ld, o) for x, o, (r, c, ld) in zip(xs, outs, shapes)])()
+    for x, o, (r, c, ld) in zip(xs, refs, shapes):
+        engine.call("dj_colsum_direct", x, r, c, ld, o, 0)
+    torch.cuda.synchronize()
+    for o, ref in zip(outs, refs):
+        assert torch.equal(o, ref)
