@@ -101,23 +101,40 @@ def query(name, *args):
 
 _TUNED = {}   # conv geometry key -> (ms, cfg, splits), process-wide
 _TUNE_DB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gfx950_conv.json")
-_DB = None    # "dir,geometry..." -> [cfg, splits, ms]: tile choices measured once on an MI355X and shipped in-tree
+_TUNE_DB_LOWP = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gfx950_conv_f16.json")
+_DB = {}      # compute mode -> {"dir,geometry...": [cfg, splits, ms]}: tile choices measured on an MI355X, shipped in-tree
 
 
 def _tune_db():
     """The in-tree table of measured tile choices (like a find-db: geometry -> kernel variant): [cfg, splits, ms alone]
     per geometry, plus a trailing 1 where tools/tune_in_step.py replaced the fastest-alone choice by the one that makes
-    the whole training step fastest.  Geometries it does not hold are timed at plan time; DJ_TUNE_DB=path selects
-    another file, DJ_TUNE_DB=0 ignores it."""
-    global _DB
-    if _DB is None:
-        _DB = {}
-        path = os.environ.get("DJ_TUNE_DB", _TUNE_DB)
+    the whole training step fastest.  The reduced-precision modes (K.set_floatx('float16' / 'bfloat16')) have a table
+    of their own: with an 8-deep MFMA the balance between staging and arithmetic, and with it the best tile, differs
+    (+5.8 % on the fp16 deconv SSD300 step, +3.1 % on ssd_custom).  Geometries a table does not hold are timed at plan
+    time; DJ_TUNE_DB=path selects another file, DJ_TUNE_DB=0 ignores the tables."""
+    mode = int(_lib.load().dj_get_compute_mode())
+    if mode not in _DB:
+        _DB[mode] = {}
+        default = _TUNE_DB_LOWP if mode != 0 and os.path.exists(_TUNE_DB_LOWP) else _TUNE_DB
+        path = os.environ.get("DJ_TUNE_DB", default)
         if path != "0" and os.path.exists(path):
             import json
             with open(path) as f:
-                _DB = json.load(f).get("entries", {})
-    return _DB
+                _DB[mode] = json.load(f).get("entries", {})
+    return _DB[mode]
+
+
+def reset_tuning():
+    """Forget the choices registered so far (the arithmetic mode changed: another table applies)."""
+    lib = _lib.load()
+    names = [n for n, _ in _lib.ConvDesc._fields_][:15]
+    for key in list(_TUNED):
+        desc = _lib.ConvDesc()
+        for n, v in zip(names, key[1:]):
+            setattr(desc, n, int(v))
+        desc.ld_x, desc.ld_y = desc.in_c, desc.out_c
+        lib.dj_conv2d_tune_set(int(key[0]), desc, -1, 1)
+    _TUNED.clear()
 
 
 def save_tune_db(path=None):

@@ -40,7 +40,9 @@ def set_floatx(value):
     modes = {v: k for k, v in _FLOATX.items()}
     if value not in modes:
         raise ValueError("Unknown floatx type: " + str(value))
-    _lib.load().dj_set_compute_mode(modes[value])
+    if _lib.load().dj_set_compute_mode(modes[value]) != modes[value]:
+        from .. import engine
+        engine.reset_tuning()      # tile choices are per arithmetic mode (tuned/gfx950_conv.json vs ..._f16.json)
 
 
 def get_uid(prefix=""):

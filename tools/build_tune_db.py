@@ -4,10 +4,12 @@ that ships in-tree (jpeg_detection_resnet_ssd_amd/tuned/gfx950_conv.json).
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 out = sys.argv[1]
+floatx = sys.argv[2] if len(sys.argv) > 2 else "float32"     # float16: the table of the reduced-precision mode
 os.environ["DJ_TUNE_SAVE"] = out
 import torch
 from jpeg_detection_resnet_ssd_amd import workloads
 from jpeg_detection_resnet_ssd_amd.keras import backend as K
+K.set_floatx(floatx)
 t0 = time.time()
 for archi in ("deconv", "ssd_custom", "up_sampling"):
     model, sizes = workloads.build_ssd(archi)
