@@ -4,7 +4,7 @@ variant beside other work need not be the same.  This tool takes the plan of one
 the most expensive down, tries every variant (and, for weight gradients, neighbouring split-K factors) IN the step and
 keeps a change only when the whole step gets faster, re-measured A/B/A against the current choice.
 
-    python tools/tune_in_step.py deconv 32 gpurun_out/step_tune.json [max_geometries] [seconds] [protect_archi]
+    python tools/tune_in_step.py deconv 32 gpurun_out/step_tune.json [max_geometries] [seconds] [protect_archi|-] [floatx]
 
 `protect_archi`: geometries that also occur in that workload's plan are left alone (their entry was chosen there).
 
@@ -25,7 +25,10 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 out_path = sys.argv[3] if len(sys.argv) > 3 else "gpurun_out/step_tune.json"
 max_geoms = int(sys.argv[4]) if len(sys.argv) > 4 else 40
 budget_s = float(sys.argv[5]) if len(sys.argv) > 5 else 420.0
-protect = sys.argv[6] if len(sys.argv) > 6 else None
+protect = sys.argv[6] if len(sys.argv) > 6 and sys.argv[6] != "-" else None
+floatx = sys.argv[7] if len(sys.argv) > 7 else "float32"
+from jpeg_detection_resnet_ssd_amd.keras import backend as K  # noqa: E402
+K.set_floatx(floatx)
 
 lib = _lib.load()
 ncfg = lib.dj_conv2d_tune_configs()
