@@ -32,8 +32,20 @@ K.set_floatx(floatx)
 
 lib = _lib.load()
 ncfg = lib.dj_conv2d_tune_configs()
-model, sizes = workloads.build_ssd(archi)
-x, y = workloads.synthetic_batch(archi, sizes, B, fast=True)
+if archi.startswith("cls:"):      # classifier workloads (BASELINE configs 1-2): cls:deconv, cls:late_concat_rfa_thinner, cls:rgb
+    import numpy as np
+    from jpeg_detection_resnet_ssd_amd.keras.optimizers import SGD
+    from jpeg_detection_resnet_ssd_amd.vgg_jpeg_keras.networks.resnet_dct import ResNet50Custom, ResNet50RGB
+    K.clear_session()
+    model = ResNet50RGB(weights=None) if archi == "cls:rgb" else ResNet50Custom(weights=None, archi=archi[4:])
+    model.compile(optimizer=SGD(lr=0.1, momentum=0.9, decay=1e-4, nesterov=True), loss="categorical_crossentropy")
+    rng = np.random.default_rng(0)
+    x = [rng.normal(0, 30, (B,) + tuple(int(d) for d in t.shape[1:])).astype(np.float32) for t in model.inputs]
+    x = x if len(x) > 1 else x[0]
+    y = np.eye(1000, dtype=np.float32)[rng.integers(0, 1000, B)]
+else:
+    model, sizes = workloads.build_ssd(archi)
+    x, y = workloads.synthetic_batch(archi, sizes, B, fast=True)
 model.optimizer.lr = 0.0     # hundreds of steps on one batch: keep the weights (and the mining workload) where they are
 plan = model._plan(B, True, True)
 model._upload(plan, x, y)
