@@ -105,19 +105,21 @@ for key in order:
         t = step_ms(6)
         if t < best[1]:
             best = ((c, sp), t)
-    if best[0] is not None and (direction & 3) == 2:
-        c = best[0][0]
-        for sp in sorted({max(1, sp0 // 2), sp0 * 2}):
-            apply(key, c, sp)
-            t = step_ms(6)
-            if t < best[1]:
-                best = ((c, sp), t)
-    elif best[0] is None and (direction & 3) == 2:
-        for sp in sorted({max(1, sp0 // 2), sp0 * 2} - {sp0}):
-            apply(key, cfg0, sp)
-            t = step_ms(6)
-            if t < best[1]:
-                best = ((cfg0, sp), t)
+    # split-K factors around the current one at the best variant so far (weight gradients), or the small factors a
+    # forward / data-gradient GEMM can use (a forward split-K launch is followed by a ReLU pass of its own: only the
+    # step time sees that).  Forward launches that take BatchNormalization statistics (dir 4) cannot split.
+    c = best[0][0] if best[0] is not None else cfg0
+    if (direction & 3) == 2:
+        sp_opts = {max(1, sp0 // 2), sp0 * 2}
+    elif direction in (0, 1):
+        sp_opts = {1, 2, 4, 8}
+    else:
+        sp_opts = set()
+    for sp in sorted(sp_opts - {sp0}):
+        apply(key, c, sp)
+        t = step_ms(6)
+        if t < best[1]:
+            best = ((c, sp), t)
     apply(key, cfg0, sp0)
     if best[0] is None:
         continue
