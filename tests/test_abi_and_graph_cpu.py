@@ -199,3 +199,35 @@ def test_classification_config_and_horovod_scaling_rules():
     cfg.prepare_training_generators()
     x, y = cfg.train_generator[0]
     assert [a.shape for a in x] == [(64, 28, 28, 64), (64, 14, 14, 64), (64, 14, 14, 64)] and y.shape == (64, 1000)
+
+
+def test_tuning_tables_follow_the_arithmetic_mode():
+    """`K.set_floatx` switches the in-tree tile table (fp32: tuned/gfx950_conv.json, fp16/bf16 MFMA:
+    tuned/gfx950_conv_f16.json); both hold the benchmark geometries, entries are [cfg, splits, ms] with an optional
+    trailing 1 for choices made inside the training step, and every cfg index exists in the library."""
+    import json
+    from jpeg_detection_resnet_ssd_amd import _lib, engine
+    from jpeg_detection_resnet_ssd_amd.keras import backend as K
+    lib = _lib.load()
+    ncfg = lib.dj_conv2d_tune_configs()
+    key = "0,32,10,10,2048,10,10,1024,3,3,1,1,6,6,6,6"      # fc6 forward, batch 32
+    try:
+        assert K.floatx() == "float32"
+        fp32 = engine._tune_db()
+        K.set_floatx("float16")
+        half = engine._tune_db()
+        assert half is not fp32 and key in fp32 and key in half
+        K.set_floatx("bfloat16")
+        assert engine._tune_db() is not fp32
+    finally:
+        K.set_floatx("float32")
+    assert engine._tune_db() is fp32
+    for path in (engine._TUNE_DB, engine._TUNE_DB_LOWP):
+        with open(path) as f:
+            table = json.load(f)
+        assert table["arch"] == "gfx950" and table["n_configs"] == ncfg
+        for k, v in table["entries"].items():
+            assert len(k.split(",")) == 16 and len(v) in (3, 4), k
+            assert 0 <= v[0] < ncfg and v[1] >= 1, k
+            if int(k.split(",")[0]) == 4:
+                assert v[1] == 1, k           # a forward launch that takes BatchNormalization statistics cannot split K
