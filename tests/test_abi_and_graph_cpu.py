@@ -231,3 +231,16 @@ def test_tuning_tables_follow_the_arithmetic_mode():
             assert 0 <= v[0] < ncfg and v[1] >= 1, k
             if int(k.split(",")[0]) == 4:
                 assert v[1] == 1, k           # a forward launch that takes BatchNormalization statistics cannot split K
+
+
+def test_entry_scripts_and_tools_compile():
+    """The trainer / evaluation entry scripts and the measurement tools are only run on the GPU box: keep them at least
+    syntactically alive on every CPU run."""
+    import glob
+    import os
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "tools", "*.py")) + glob.glob(os.path.join(root, "*.py")))
+    assert len(files) >= 15
+    for f in files:
+        py_compile.compile(f, doraise=True)
