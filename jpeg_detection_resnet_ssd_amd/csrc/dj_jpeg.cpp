@@ -149,6 +149,9 @@ inline int decode_symbol(BitReader& br, const Huff& h) {
   return -1;
 }
 
+// 16384 x 16384 pixels at 1x1 sampling = 4 Mi blocks = 512 MB of int16 coefficients per component
+static const long kMaxBlocksPerPlane = 4L << 20;
+
 struct Decoder {
   const unsigned char* data;
   long size;
@@ -195,6 +198,9 @@ struct Decoder {
   }
 
   int parse_sof(const unsigned char* p, int len, int kind) {
+    // one frame per file: a second SOF after a scan has sized the coefficient planes would make later scans write with
+    // the new geometry into the old planes
+    if (saw_sof) return fail("second frame header (SOF) in one file");
     if (len < 6) return fail("truncated SOF");
     if (p[0] != 8) return fail("only 8-bit JPEG is supported (precision %d)", p[0]);
     height = be16(p + 1);
@@ -214,6 +220,10 @@ struct Decoder {
       if (comp[c].v > vmax) vmax = comp[c].v;
     }
     const int mcux = (width + 8 * hmax - 1) / (8 * hmax), mcuy = (height + 8 * vmax - 1) / (8 * vmax);
+    // bound the coefficient planes the scans will allocate (65535 x 65535 with 4x4 sampling would ask for 8.6 GB each)
+    if ((long)mcux * hmax * (long)mcuy * vmax > kMaxBlocksPerPlane)
+      return fail("image of %d x %d pixels exceeds the reader's limit of %ld blocks per component", width, height,
+                  kMaxBlocksPerPlane);
     for (int c = 0; c < ncomp; ++c) {
       const int cw = (width * comp[c].h + hmax - 1) / hmax, chh = (height * comp[c].v + vmax - 1) / vmax;
       comp[c].blocks_w = (cw + 7) / 8;
@@ -254,6 +264,7 @@ struct Decoder {
   int decode_scan(const unsigned char* hdr, int len, const unsigned char* ecs, const unsigned char* end,
                   const unsigned char** next) {
     if (!saw_sof) return fail("SOS before SOF");
+    if (len < 1) return fail("bad SOS");
     int ns = hdr[0];
     if (ns < 1 || ns > 4 || len < 1 + 2 * ns + 3) return fail("bad SOS");
     Component* sc[4];

@@ -82,6 +82,88 @@ def test_errors(gold, j2d):
     j2d.loads(data[:len(data) // 2])               # truncated scan: zero-filled tail like libjpeg, must not crash
 
 
+def _hostile_inputs(gold):
+    """Crafted files (name -> bytes) that must be REJECTED cleanly (a second SOF after a scan had sized the
+    coefficient planes made the next scan write past them)."""
+    odd, big = gold["odd_53x37_q90/jpeg"].tobytes(), gold["ssd300_default/jpeg"].tobytes()
+    assert odd[-2:] == b"\xff\xd9" and big[:2] == b"\xff\xd8"
+    sos = big.index(b"\xff\xda")
+    sof = big.index(b"\xff\xc0")
+    out = {
+        "two_frames": odd[:-2] + big[2:],                                   # small frame, scan, LARGER frame, scan
+        "two_frames_small_second": big[:-2] + odd[2:],
+        "sos_len2_at_eof": big[:sos] + b"\xff\xda\x00\x02",                # SOS with an empty body as the last bytes
+        "sos_len3": big[:sos] + b"\xff\xda\x00\x03\x03",
+        "huge_4x4": big[:sof + 5] + b"\xff\xff\xff\xff" + big[sof + 9:sof + 11] + b"\x44" + big[sof + 12:],
+        "sof_zero_components": big[:sof + 9] + b"\x00" + big[sof + 10:],
+        "garbage_after_soi": b"\xff\xd8" + bytes(range(256)) * 8,
+        "scan_without_tables": big[:2] + big[sof:],
+    }
+    rng = np.random.default_rng(5)
+    for i in range(6):                                                       # random byte flips inside the headers
+        b = bytearray(big)
+        for pos in rng.integers(2, sos + 12, size=4):
+            b[int(pos)] = int(rng.integers(0, 256))
+        out["flip_%d" % i] = bytes(b)
+    return out
+
+
+def test_hostile_files_are_rejected(gold, j2d):
+    bad = _hostile_inputs(gold)
+    for name in ("two_frames", "two_frames_small_second", "sos_len2_at_eof", "sos_len3", "huge_4x4",
+                 "sof_zero_components", "garbage_after_soi", "scan_without_tables"):
+        with pytest.raises(ValueError):
+            j2d.loads(bad[name])
+    for name in [k for k in bad if k.startswith("flip_")]:                   # may decode or fail, must not crash
+        try:
+            j2d.loads(bad[name])
+        except ValueError:
+            pass
+    with pytest.raises(ValueError):
+        j2d.decode_batch([bad["two_frames"]] * 2, (7, 5), (4, 3))
+
+
+def test_hostile_files_under_address_sanitizer(gold, tmp_path):
+    """The same files through an AddressSanitizer + UBSan build of dj_jpeg.cpp (CPU build only; harness:
+    tests/jpeg_asan_harness.cpp): no report, every crafted file answered with rc = -1, good files with rc = 0."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "jpeg_asan")
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           os.path.join(root, "tests", "jpeg_asan_harness.cpp"),
+           os.path.join(root, "jpeg_detection_resnet_ssd_amd", "csrc", "dj_jpeg.cpp"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and "sanitizer" in (r.stderr or "").lower():
+        pytest.skip("sanitizer runtime not installed: " + r.stderr[-200:])
+    assert r.returncode == 0, r.stderr[-2000:]
+    files, must_fail = [], set()
+    for name, data in _hostile_inputs(gold).items():
+        path = tmp_path / (name + ".jpg")
+        path.write_bytes(data)
+        files.append(str(path))
+        if not name.startswith("flip_"):
+            must_fail.add(str(path))
+    good = []
+    for name in names(gold):
+        if name == "progressive":
+            continue
+        path = tmp_path / ("ok_" + name + ".jpg")
+        path.write_bytes(gold[name + "/jpeg"].tobytes())
+        good.append(str(path))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe] + files + good, capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, \
+        (r.stdout[-1500:], r.stderr[-3000:])
+    lines = {ln.split(": ", 1)[0]: ln for ln in r.stdout.splitlines() if ": info=" in ln}
+    for f in must_fail:
+        assert " rc=-1" in lines[f], lines[f]
+    for f in good:
+        assert " rc=0" in lines[f], lines[f]
+
+
 def test_pil_round_trip_if_available(j2d):
     """Coefficients -> dequantise -> IDCT reproduces PIL's own decode of the same file (sanity of the whole chain)."""
     Image = pytest.importorskip("PIL.Image")
