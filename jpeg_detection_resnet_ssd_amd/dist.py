@@ -103,6 +103,11 @@ class DataParallel(object):
         model.dist = self
         self.exchange = None
         self._attached = set()
+        # training plans lowered BEFORE the model became data parallel (train_on_batch, or the trainer's warm-up, called
+        # first) have no all-reduce in their launch lists: splice it in now, or the replicas would silently diverge
+        for key, plan in list(model._plans.items()):
+            if plan.training and key[2]:
+                self.attach(plan)
 
     def broadcast_weights(self, src=0):
         """Rank `src`'s weights (trainable and BatchNormalization state) to every rank."""
@@ -132,7 +137,13 @@ class DataParallel(object):
         self._attached.add(id(plan))
         self.n_buckets = len(buckets)
 
-    def finish_gradients(self):
+    def finish_gradients(self, plan=None):
+        """Wait for the step's all-reduces; -> the factor (1/world) the optimizer applies to the summed gradients."""
+        if not dist.is_initialized():
+            return 1.0
+        if plan is not None and id(plan) not in self._attached:
+            raise RuntimeError("data parallel: the training plan that just ran has no gradient exchange attached "
+                               "(its gradients are per-rank): replicas would diverge")
         if self.exchange is None:
             return 1.0
         return self.exchange.finish()

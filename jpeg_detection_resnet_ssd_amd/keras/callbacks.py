@@ -78,8 +78,15 @@ class ModelCheckpoint(Callback):
         self.save_best_only = save_best_only
         self.save_weights_only = save_weights_only
         self.period = period
-        self.best = math.inf if ("acc" not in monitor or mode == "min") else -math.inf
-        self.greater = not ("acc" not in monitor or mode == "min")
+        # Keras 2.2.4 ModelCheckpoint: explicit 'min' / 'max'; 'auto' (and unknown modes, with a warning there) means
+        # max when the monitored name contains 'acc' or starts with 'fmeasure', min otherwise
+        if mode == "min":
+            self.greater = False
+        elif mode == "max":
+            self.greater = True
+        else:
+            self.greater = ("acc" in monitor) or monitor.startswith("fmeasure")
+        self.best = -math.inf if self.greater else math.inf
         self.since = 0
 
     def on_epoch_end(self, epoch, logs=None):
@@ -107,9 +114,16 @@ class ReduceLROnPlateau(Callback):
                  cooldown=0, min_lr=0, **kwargs):
         self.monitor, self.factor, self.patience = monitor, factor, patience
         self.verbose, self.min_delta, self.cooldown, self.min_lr = verbose, min_delta, cooldown, min_lr
-        self.best = math.inf
+        if factor >= 1.0:
+            raise ValueError("ReduceLROnPlateau does not support a factor >= 1.0.")
+        # Keras: 'min', or 'auto' with a monitor that does not contain 'acc' -> improvement = decrease
+        self.greater = mode == "max" or (mode not in ("min", "max") and "acc" in monitor)
+        self.best = -math.inf if self.greater else math.inf
         self.wait = 0
         self.cooldown_counter = 0
+
+    def _improved(self, cur):
+        return cur > self.best + self.min_delta if self.greater else cur < self.best - self.min_delta
 
     def on_epoch_end(self, epoch, logs=None):
         cur = (logs or {}).get(self.monitor)
@@ -118,7 +132,7 @@ class ReduceLROnPlateau(Callback):
         if self.cooldown_counter > 0:
             self.cooldown_counter -= 1
             self.wait = 0
-        if cur < self.best - self.min_delta:
+        if self._improved(cur):
             self.best = cur
             self.wait = 0
         elif self.cooldown_counter <= 0:
@@ -136,19 +150,23 @@ class ReduceLROnPlateau(Callback):
 class EarlyStopping(Callback):
     def __init__(self, monitor="val_loss", min_delta=0, patience=0, verbose=0, mode="auto", **kwargs):
         self.monitor, self.min_delta, self.patience, self.verbose = monitor, abs(min_delta), patience, verbose
-        self.best = math.inf
+        self.greater = mode == "max" or (mode not in ("min", "max") and "acc" in monitor)
+        self.best = -math.inf if self.greater else math.inf
         self.wait = 0
+        self.stopped_epoch = 0
 
     def on_epoch_end(self, epoch, logs=None):
         cur = (logs or {}).get(self.monitor)
         if cur is None:
             return
-        if cur < self.best - self.min_delta:
+        better = cur > self.best + self.min_delta if self.greater else cur < self.best - self.min_delta
+        if better:
             self.best = cur
             self.wait = 0
         else:
             self.wait += 1
             if self.wait >= self.patience:
+                self.stopped_epoch = epoch
                 self.model.stop_training = True
 
 

@@ -58,6 +58,7 @@ class Model(object):
         self._store = None
         self._device = None
         self.dist = None          # set by dist.DataParallel
+        self._last_train_plan = None
         self.last_step_info = {}
 
     # ---- graph queries ------------------------------------------------------------
@@ -225,10 +226,36 @@ class Model(object):
             self.loss = ("cce", None)
         elif loss is None:
             self.loss = None
+        elif callable(loss):
+            # Keras loss protocol (localisation_part/training_dct_pascal_j2d_resnet.py:154-156): any
+            # loss(y_true, y_pred) -> (batch,) written in torch ops.  It is evaluated on the device-resident tensors and
+            # differentiated by torch autograd with respect to y_pred only; the model's own backward pass (the HIP
+            # launch list) starts from that gradient.  Checked here, at compile time, on a tiny probe so that a callable
+            # that cannot take device tensors fails now and not in the middle of fit_generator.
+            self._probe_loss(loss)
+            self.loss = ("callable", loss)
         else:
-            raise NotImplementedError("loss %r has no MI355X lowering (SSDLoss.compute_loss and "
-                                      "categorical_crossentropy do)" % (loss,))
+            raise NotImplementedError("loss %r has no MI355X lowering: pass SSDLoss(...).compute_loss, "
+                                      "'categorical_crossentropy', or a callable loss(y_true, y_pred) written in torch "
+                                      "ops on CUDA tensors" % (loss,))
         self._plans = {}
+
+    def _probe_loss(self, loss):
+        if not torch.cuda.is_available():
+            return      # graph building without a GPU (structure tests): the probe runs on the first GPU compile
+        shape = (2,) + tuple(int(d) for d in self.outputs[0].shape[1:])
+        dev = torch.device("cuda", torch.cuda.current_device())
+        yp = torch.rand(shape, device=dev).requires_grad_(True)
+        yt = torch.rand(shape, device=dev)
+        try:
+            val = loss(yt, yp)
+            if not (isinstance(val, torch.Tensor) and val.requires_grad):
+                raise TypeError("it returned %r, not a torch tensor that depends on y_pred" % (type(val).__name__,))
+            val.mean().backward()
+        except Exception as e:
+            raise TypeError("loss %r cannot be compiled: a custom loss must be loss(y_true, y_pred) -> (batch,) in "
+                            "differentiable torch ops on CUDA tensors (probe on shape %s failed: %s: %s)"
+                            % (loss, shape, type(e).__name__, e))
 
     # ---- plans ------------------------------------------------------------------------
     def _plan(self, batch_size, training, with_loss, external_grad=False):
@@ -310,6 +337,27 @@ class Model(object):
                 plan.emit_bwd(lambda: call("dj_ssd_loss_bwd", yt, yp, nbox, n_cls, alpha, 1.0, ws, out5, d))
 
             plan.on_backward(build_backward)
+        elif kind == "callable":
+            out = plan.loss_out
+            dpred = plan.empty(*yp.shape) if plan.training else None
+
+            def loss_fwd():
+                if plan.targets_event is not None:   # y_true is being encoded on the side stream (see _upload)
+                    torch.cuda.current_stream().wait_event(plan.targets_event)
+                    plan.targets_event = None
+                # Keras: total loss = mean over the batch of loss(y_true, y_pred); torch autograd supplies d/d y_pred
+                leaf = yp.detach().requires_grad_(plan.training)
+                with torch.enable_grad():
+                    val = obj(yt, leaf).mean()
+                    if plan.training:
+                        dpred.copy_(torch.autograd.grad(val, leaf)[0])
+                out[0:1].copy_(val.detach().reshape(1))
+            plan.emit(loss_fwd)
+
+            def build_backward():
+                plan.set_grad_ref(pred, GradRef(dpred))
+
+            plan.on_backward(build_backward)
         else:
             rows, c = yp.shape[0], yp.shape[1]
             loss_rows = plan.empty(rows)
@@ -366,7 +414,7 @@ class Model(object):
         lr_t = opt.current_lr()
         scale = 1.0
         if self.dist is not None:
-            scale = self.dist.finish_gradients()
+            scale = self.dist.finish_gradients(self._last_train_plan)
         st["sumsq"].zero_()
         for i, (a, b, l2) in enumerate(st["segments"]):
             if b <= a:
@@ -378,6 +426,7 @@ class Model(object):
 
     def run_train_step(self, plan):
         """Forward, backward and optimizer step on buffers already resident in HBM (no host sync)."""
+        self._last_train_plan = plan
         plan.run_forward()
         plan.run_backward()
         self._apply_optimizer()
@@ -468,6 +517,12 @@ class Model(object):
             cb.on_train_begin()
         it = iter(generator)
         val_it = iter(validation_data) if validation_data is not None and not isinstance(validation_data, tuple) else None
+        if val_it is not None and validation_steps is None:
+            if hasattr(validation_data, "__len__"):     # keras.utils.Sequence
+                validation_steps = len(validation_data)
+            else:
+                raise ValueError("`validation_steps=None` is only valid for a generator based on the `keras.utils.Sequence`"
+                                 " class. Please specify `validation_steps` or use the `keras.utils.Sequence` class.")
         self.stop_training = False
         rank0 = self.dist is None or self.dist.rank == 0
         # Keras runs the generator in a background enqueuer (`workers`, `max_queue_size`); so does this loop, with one

@@ -140,6 +140,31 @@ def backbone(net, archi, inputs, taps):
         y_in, cbcr_in = inputs
         x = torch.cat([y_in, ko.upsampling_nearest_2x(cbcr_in)], dim=-1)
         return _rfa_trunk(net, net.bn(x))
+    if archi == "late_concat_more_channels":
+        # C/vgg_jpeg_keras/networks/resnet_dct.py:529-566: the late-concat graph with 768-channel Y stages (the filter
+        # counts come with the weights) and stage-3 identity blocks named b1 / c1 / d1
+        y_in, cbcr_in = inputs
+        y = _y_prefix(net, net.bn(y_in))
+        y = net.conv_block(y, 3, 2, "a4")
+        cbcr = net.conv_block(net.bn(cbcr_in), 1, 2, "a5", (1, 1))
+        x = torch.cat([y, cbcr], dim=-1)
+        for b in ("b1", "c1", "d1"):
+            x = net.identity_block(x, 3, 3, b)
+        x = net.conv_block(x, 3, 4, "a")
+        for b in "bcdef":
+            x = net.identity_block(x, 3, 4, b)
+        return x
+    if archi == "up_sampling_plain":
+        # C/vgg_jpeg_keras/networks/resnet_dct.py:454-487 (classifier `archi="up_sampling"`): no RFA prefix
+        y_in, cbcr_in = inputs
+        x = net.bn(torch.cat([y_in, ko.upsampling_nearest_2x(cbcr_in)], dim=-1))
+        x = net.conv_block(x, 3, 3, "a1", (1, 1))
+        for b in "bcd":
+            x = net.identity_block(x, 3, 3, b)
+        x = net.conv_block(x, 3, 4, "a")
+        for b in "bcdef":
+            x = net.identity_block(x, 3, 4, b)
+        return x
     if archi == "cb5_only":
         y_in, cbcr_in = inputs
         y = _y_prefix(net, net.bn(y_in))
@@ -243,6 +268,8 @@ def ssd_forward(weights, inputs, archi, training=True, cfg=TRAIN_SSD_ARGS):
 def classifier_forward(weights, inputs, archi, training=True):
     """ResNet50Custom(archi=...) (C/vgg_jpeg_keras/networks/resnet_dct.py:392-417): -> (probs, net)."""
     net = Net(weights, training)
+    if archi == "up_sampling":     # the classifier dispatches this name to the plain graph, the SSD builder to the RFA one
+        archi = "up_sampling_plain"
     x = _block5(net, backbone(net, archi, inputs, {}))
     x = ko.global_average_pooling(x)
     logits = ko.dense(x, weights["fc1000/kernel"], weights["fc1000/bias"])

@@ -13,7 +13,8 @@ def rel_err(a, ref):
     return float((a - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
 
 
-@pytest.mark.parametrize("archi,batch", [("resnet_rgb", 2), ("deconv", 4), ("late_concat_rfa_thinner", 2)])
+@pytest.mark.parametrize("archi,batch", [("resnet_rgb", 2), ("deconv", 4), ("late_concat_rfa_thinner", 2),
+                                         ("late_concat_more_channels", 2), ("up_sampling", 2)])
 def test_classifier_training_step(archi, batch, cuda):
     from jpeg_detection_resnet_ssd_amd.data import synthetic_dct as sd
     from jpeg_detection_resnet_ssd_amd.keras import backend as K
@@ -58,4 +59,5 @@ def test_classifier_training_step(archi, batch, cuda):
     assert rel_err(probs, ref["probs"]) <= 1e-3
     assert abs(loss - ref["loss"]) <= 1e-3 * abs(ref["loss"])
     from test_ssd_gpu import check_gradients_and_update
-    check_gradients_and_update(grads, ref, ref32, w0, w1)
+    check_gradients_and_update(grads, ref, ref32, w0, w1, lr=0.1, momentum=0.9, decay=1e-4, iterations=3, nesterov=True,
+                               min_strict=3)

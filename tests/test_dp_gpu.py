@@ -23,13 +23,17 @@ def _free_port():
 
 
 def _rank_main(rank, world, port, out):
+    # DJ_TEST_DP_BACKEND=nccl with DJ_TEST_DP_GPUS >= world runs the same checks over RCCL, one GPU per rank (a lease
+    # with two or more cards); the default is what a one-GPU box can do: both ranks on card 0, gloo transport
+    backend = os.environ.get("DJ_TEST_DP_BACKEND", "gloo")
+    local = rank if int(os.environ.get("DJ_TEST_DP_GPUS", "1")) >= world else 0
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0")
+                      LOCAL_RANK=str(local))
     import torch
     from jpeg_detection_resnet_ssd_amd import dist as dj
     from jpeg_detection_resnet_ssd_amd import workloads
-    dj.init_from_env(backend="gloo")
-    torch.cuda.set_device(0)
+    dj.init_from_env(backend=backend)
+    torch.cuda.set_device(local)
     model, sizes = workloads.build_ssd(ARCHI, weight_seed=42 + rank)   # different init: the broadcast must fix it
     model._ensure_params()
     dp = dj.DataParallel(model, bucket_mb=16)
@@ -72,7 +76,7 @@ def test_two_rank_step_matches_gradient_averaging(cuda, monkeypatch):
     class FakeDist:
         rank = 0
 
-        def finish_gradients(self):
+        def finish_gradients(self, plan=None):
             return 0.5
 
     plan = model._plan(BATCH, True, True)
@@ -96,3 +100,72 @@ def test_two_rank_step_matches_gradient_averaging(cuda, monkeypatch):
     # split-K gradient GEMMs accumulate with fp32 atomics in arrival order: two runs of the same step differ by a few 1e-6,
     # occasionally 5e-5 after two steps; a missing 1/world or a dropped bucket shows up at 1e-2 and above
     assert err <= 2e-4, err
+
+
+def _one_rank_rccl_main(port, out):
+    """Child process: a 1-rank RCCL communicator (backend "nccl"), which is what a one-GPU box can run of the real
+    exchange: ProcessGroupNCCL stream semantics, bucketed all-reduces spliced into the backward launch list and issued
+    with the side stream current (Plan.after_both_streams), Work.wait() on the main stream, 1/world in the SGD kernel."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      DJ_FORCE_DIST="1")
+    import torch
+    from jpeg_detection_resnet_ssd_amd import dist as dj
+    from jpeg_detection_resnet_ssd_amd import workloads
+    model, sizes = workloads.build_ssd(ARCHI, weight_seed=42)
+    model._ensure_params()
+    st = model._store
+    x, y = workloads.synthetic_batch(ARCHI, sizes, BATCH, seed=1234)
+    w_init, state_init = model.flat_trainable.clone(), model.flat_all.clone()
+
+    def steps():
+        model.flat_all.copy_(state_init)
+        st["vel"].zero_()
+        model.optimizer.iterations = 0
+        losses = [model.train_on_batch(x, y) for _ in range(STEPS)]
+        torch.cuda.synchronize()
+        return model.flat_trainable.detach().cpu().numpy().copy(), losses
+
+    w_plain, l_plain = steps()                 # not distributed; this also lowers and caches the training plan
+    w_plain2, _ = steps()                      # run-to-run spread of the fp32 split-K atomics, the yardstick below
+    rank, world, _ = dj.init_from_env()        # backend None -> "nccl" on a GPU box
+    assert torch.distributed.get_backend() == "nccl" and (rank, world) == (0, 1)
+    dp = dj.DataParallel(model, bucket_mb=16)  # AFTER the plan was cached: the constructor must splice the exchange in
+    plan = model._plan(BATCH, True, True)
+    assert id(plan) in dp._attached
+    dp.broadcast_weights(0)
+    launched = []
+    orig = dp.exchange.launch
+    dp.exchange.launch = lambda ranges: (launched.append(ranges), orig(ranges))[1]
+    w_dist, l_dist = steps()
+    covered = sorted(r for rs in launched[:dp.n_buckets] for r in rs)
+    w0 = w_init.cpu().numpy()
+    out.put(dict(step=float(np.abs(w_plain - w0).max()), spread=float(np.abs(w_plain - w_plain2).max()),
+                 err=float(np.abs(w_dist - w_plain).max()), l_plain=l_plain, l_dist=l_dist,
+                 n_buckets=dp.n_buckets, n_launch=len(launched), covered=covered, n_train=int(st["n_train"])))
+    torch.distributed.destroy_process_group()
+
+
+def test_one_rank_rccl_exchange_in_the_step(cuda, monkeypatch):
+    """The RCCL code path inside the driver-run suite.  With one rank the all-reduce is the identity
+    and 1/world = 1, so the distributed steps must give the weights of the plain steps -- to the run-to-run spread of the
+    split-K fp32 atomics (two plain runs are compared for that spread; with DJ_AUTOTUNE=0 both are usually 0)."""
+    monkeypatch.setenv("DJ_AUTOTUNE", "0")
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    p = ctx.Process(target=_one_rank_rccl_main, args=(_free_port(), out))
+    p.start()
+    res = out.get(timeout=900)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert res["n_buckets"] >= 2 and res["n_launch"] == STEPS * res["n_buckets"]
+    # the buckets tile the flat gradient buffer exactly once
+    pos = 0
+    for lo, hi in res["covered"]:
+        assert lo == pos and hi > lo, (lo, hi, pos)
+        pos = hi
+    assert pos == res["n_train"]
+    step, spread, err = res["step"], res["spread"], res["err"]
+    print("one-rank RCCL: %d buckets, |dw| max %.3e, plain-vs-plain %.3e, dist-vs-plain %.3e"
+          % (res["n_buckets"], step, spread, err))
+    assert step > 0 and err <= max(4 * spread, 2e-4 * step)
+    assert res["l_dist"] == pytest.approx(res["l_plain"], rel=1e-5)

@@ -1,0 +1,295 @@
+"""Per-launch oracle parity AT THE BENCHED SIZE ("make the parity evidence bite").
+
+The training plan of the bench workload (SSD300 ResNet50-DCT `deconv`, batch 32) is lowered with the in-tree tuning
+table (DJ_AUTOTUNE=table: exactly the registered tile variant / split-K factor of every geometry), one forward +
+backward pass is run on the bench's synthetic batch, and every DISTINCT launch of the hot kernels is checked, at the
+moment it is issued and on its own operands as they sit in HBM, against the CPU oracle in fp64:
+
+  * implicit-GEMM convolutions in all three directions -- forward (with the BatchNormalization(+ReLU) prologue, the
+    residual-add prologue, the fused bias / ReLU epilogue and the BN partial statistics), input gradient (plain,
+    accumulating, strided scatter, Conv2DTranspose forward) and weight gradient (split-K into the cleared buffer):
+    1e-3 max-norm forward, 1e-3 relative L2 for the gradients;
+  * every training-mode BatchNormalization: the scale / shift the forward pass derived from the batch statistics, and
+    the backward pass (dj_bn_bwd_reduce + finalize + apply) -- dz, dgamma, dbeta and the masked shortcut gradient --
+    against torch.autograd through oracle.keras_ops.batch_norm_train on the same z and upstream gradient: 1e-3 rel-L2.
+
+This is teacher forcing in the direction that needs no second pass: each layer's kernel is fed by the engine's own
+upstream tensor and compared with the oracle's op on that same tensor, so no error of an earlier layer can hide or
+compound.  Distinct = (entry point, geometry, prologue / epilogue flags); repeats of a geometry run the same code on
+other data and are skipped to keep the oracle's CPU time to about a minute."""
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import keras_ops as ko
+
+pytestmark = pytest.mark.gpu
+
+ARCHI, BATCH = "deconv", 32
+TOL = 1e-3
+
+
+def _f64(t):
+    return None if t is None else t.detach().to("cpu", torch.float64)
+
+
+def _pad_for(desc):
+    """Explicit (left, right, top, bottom) zero padding that reproduces the descriptor's geometry (may crop)."""
+    pb = (desc.out_h - 1) * desc.stride_h + (desc.kernel_h - 1) * desc.dilation_h + 1 - desc.in_h - desc.pad_top
+    pr = (desc.out_w - 1) * desc.stride_w + (desc.kernel_w - 1) * desc.dilation_w + 1 - desc.in_w - desc.pad_left
+    return (desc.pad_left, pr, desc.pad_top, pb)
+
+
+def _oracle_conv(a, w, bias, desc):
+    """ko.conv2d with the descriptor's explicit padding: a (B,H,W,Cin) fp64, w HWIO."""
+    l, r, t, b = _pad_for(desc)
+    a = F.pad(a.permute(0, 3, 1, 2), (l, r, t, b)).permute(0, 2, 3, 1)
+    return ko.conv2d(a, w, bias, (desc.stride_h, desc.stride_w), "valid", (desc.dilation_h, desc.dilation_w))
+
+
+def _rel_l2(got, ref):
+    return float((got - ref).norm()) / (float(ref.norm()) + 1e-300)
+
+
+def _rel_max(got, ref):
+    return float((got - ref).abs().max()) / (float(ref.abs().max()) + 1e-300)
+
+
+class Replay(object):
+    """Wraps the kernels.conv2d_* wrappers and the BatchNormalization launches of `engine.call`."""
+
+    def __init__(self):
+        self.seen = set()
+        self.rows = []          # (kind, geometry, metric name, value)
+        self.cpu_s = 0.0
+        self.bn_fin = {}        # id(k0 tensor) -> args of the dj_bn_bwd_finalize that produced k0 / k1 / k2
+        self.bn_params = {}     # data_ptr(gamma) -> (gamma, beta, eps)
+
+    # ---- convolutions ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _geom(desc):
+        return tuple(getattr(desc, n) for n, _ in type(desc)._fields_[:15])
+
+    def _note(self, kind, geom, **metrics):
+        for k, v in metrics.items():
+            self.rows.append((kind, geom, k, v))
+
+    def fwd(self, orig):
+        def run(desc, x, w, bias, y, pro_scale=None, pro_shift=None, pro_relu=False, relu=False, stats=None,
+                y_zeroed=False):
+            key = ("fwd", self._geom(desc), pro_scale is not None, bool(pro_relu), bool(relu), stats is not None,
+                   bool(y_zeroed), bias is not None)
+            if key in self.seen:
+                return orig(desc, x, w, bias, y, pro_scale, pro_shift, pro_relu, relu, stats, y_zeroed)
+            self.seen.add(key)
+            before = y.clone() if y_zeroed else None
+            orig(desc, x, w, bias, y, pro_scale, pro_shift, pro_relu, relu, stats, y_zeroed)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            a = _f64(x)
+            if pro_scale is not None:
+                a = a * _f64(pro_scale) + _f64(pro_shift)
+                if pro_relu:
+                    a = ko.relu(a)
+            raw = _oracle_conv(a, _f64(w), None, desc)
+            ref = raw + _f64(bias) if bias is not None else raw
+            if relu:
+                ref = ko.relu(ref)
+            if before is not None:
+                assert float(before.abs().max()) == 0.0, "split-K forward output was not cleared"
+            m = dict(y_max=_rel_max(_f64(y), ref))
+            if stats is not None:
+                st = _f64(stats).sum(dim=0)
+                s_ref, q_ref = raw.sum(dim=(0, 1, 2)), (raw * raw).sum(dim=(0, 1, 2))
+                rows = raw.shape[0] * raw.shape[1] * raw.shape[2]
+                # a column sum may cancel: measure it against sqrt(rows * sum of squares), its natural scale
+                m["stats_sum"] = float(((st[0] - s_ref).abs() / (rows * q_ref).sqrt().clamp_min(1e-30)).max())
+                m["stats_sq"] = _rel_max(st[1], q_ref)
+            self.cpu_s += time.time() - t0
+            self._note("fwd", key[1:], **m)
+        return run
+
+    def fwd_addrelu(self, orig):
+        def run(desc, x, w, bias, y, pro_scale, pro_shift, res, res_scale=None, res_shift=None, sum_out=None,
+                relu=False, stats=None):
+            key = ("fwd_addrelu", self._geom(desc), res_scale is not None, sum_out is not None, bool(relu),
+                   stats is not None)
+            if key in self.seen:
+                return orig(desc, x, w, bias, y, pro_scale, pro_shift, res, res_scale, res_shift, sum_out, relu, stats)
+            self.seen.add(key)
+            orig(desc, x, w, bias, y, pro_scale, pro_shift, res, res_scale, res_shift, sum_out, relu, stats)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            r = _f64(res)
+            if res_scale is not None:
+                r = r * _f64(res_scale) + _f64(res_shift)
+            a = ko.relu(_f64(x) * _f64(pro_scale) + _f64(pro_shift) + r)
+            raw = _oracle_conv(a, _f64(w), None, desc)
+            ref = raw + _f64(bias) if bias is not None else raw
+            if relu:
+                ref = ko.relu(ref)
+            m = dict(y_max=_rel_max(_f64(y), ref))
+            if sum_out is not None:
+                m["sum_max"] = _rel_max(_f64(sum_out), a)
+            if stats is not None:
+                st = _f64(stats).sum(dim=0)
+                q_ref = (raw * raw).sum(dim=(0, 1, 2))
+                rows = raw.shape[0] * raw.shape[1] * raw.shape[2]
+                m["stats_sum"] = float(((st[0] - raw.sum(dim=(0, 1, 2))).abs() / (rows * q_ref).sqrt().clamp_min(1e-30)).max())
+                m["stats_sq"] = _rel_max(st[1], q_ref)
+            self.cpu_s += time.time() - t0
+            self._note("fwd_addrelu", key[1:], **m)
+        return run
+
+    def dgrad(self, orig):
+        def run(desc, dy, w, dx, bias=None, beta=False):
+            key = ("dgrad", self._geom(desc), bias is not None, bool(beta))
+            if key in self.seen:
+                return orig(desc, dy, w, dx, bias, beta)
+            self.seen.add(key)
+            before = dx.clone() if beta else None
+            orig(desc, dy, w, dx, bias, beta)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            x0 = torch.zeros(tuple(dx.shape), dtype=torch.float64, requires_grad=True)
+            _oracle_conv(x0, _f64(w), None, desc).backward(_f64(dy))
+            ref = x0.grad
+            if bias is not None:          # Conv2DTranspose forward: + bias[channel of dx]
+                ref = ref + _f64(bias)
+            got = _f64(dx) - _f64(before) if before is not None else _f64(dx)
+            self.cpu_s += time.time() - t0
+            self._note("dgrad", key[1:], dx_l2=_rel_l2(got, ref), dx_max=_rel_max(got, ref))
+        return run
+
+    def wgrad(self, orig):
+        def run(desc, x, dy, dw, pro_scale=None, pro_shift=None, pro_relu=False, dw_zeroed=False):
+            key = ("wgrad", self._geom(desc), pro_scale is not None, bool(pro_relu), bool(dw_zeroed))
+            if key in self.seen:
+                return orig(desc, x, dy, dw, pro_scale, pro_shift, pro_relu, dw_zeroed)
+            self.seen.add(key)
+            before = dw.clone() if dw_zeroed else None
+            orig(desc, x, dy, dw, pro_scale, pro_shift, pro_relu, dw_zeroed)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            a = _f64(x)
+            if pro_scale is not None:
+                a = a * _f64(pro_scale) + _f64(pro_shift)
+                if pro_relu:
+                    a = ko.relu(a)
+            w0 = torch.zeros(tuple(dw.shape), dtype=torch.float64, requires_grad=True)
+            _oracle_conv(a, w0, None, desc).backward(_f64(dy))
+            if before is not None:
+                assert float(before.abs().max()) == 0.0, "weight-gradient buffer was not cleared before its only writer"
+            self.cpu_s += time.time() - t0
+            self._note("wgrad", key[1:], dw_l2=_rel_l2(_f64(dw), w0.grad), dw_max=_rel_max(_f64(dw), w0.grad))
+        return run
+
+    # ---- BatchNormalization ------------------------------------------------------------------------------------
+    def call(self, orig):
+        def run(name, *args):
+            if name == "dj_bn_bwd_finalize":
+                # (part, nr, rows, gamma, mean, invstd, dgamma, dbeta, k0, k1, k2, c)
+                self.bn_fin[args[8].data_ptr()] = args
+                return orig(name, *args)
+            if name != "dj_bn_bwd_apply":
+                return orig(name, *args)
+            (dy, ld_dy, z, ld_z, mask_y, ld_y, scale, shift, mode, k0, k1, k2, dz, ld_dz, rows, c, dm, ld_dm,
+             dm_beta) = args
+            fin = self.bn_fin[k0.data_ptr()]
+            gamma, dgamma, dbeta = fin[3], fin[6], fin[7]
+            key = ("bn", int(rows), int(c), int(mode), dm is not None, int(dm_beta), int(ld_dy), int(ld_z))
+            if key in self.seen:
+                return orig(name, *args)
+            self.seen.add(key)
+            dm_before = dm.clone() if (dm is not None and dm_beta) else None
+            orig(name, *args)
+            torch.cuda.synchronize()
+            t0 = time.time()
+
+            def rows_view(t, ld):
+                # (rows, c) view of a buffer whose pixel stride may exceed c (channel slice of a concat buffer)
+                return _f64(torch.as_strided(t, (int(rows), int(c)), (int(ld), 1)))
+
+            z64 = rows_view(z, ld_z).requires_grad_(True)
+            g64 = _f64(gamma).clone().requires_grad_(True)
+            beta_param = self.bn_params[gamma.data_ptr()][1]
+            b64 = _f64(beta_param).clone().requires_grad_(True)
+            y, mean, var = ko.batch_norm_train(z64.view(1, 1, int(rows), int(c)), g64, b64)
+            y = y.view(int(rows), int(c))
+            up = rows_view(dy, ld_dy)
+            if mode == 1:
+                up = up * (rows_view(mask_y, ld_y) > 0).to(torch.float64)
+            out = ko.relu(y) if mode == 2 else y
+            (out * up).sum().backward()
+            invstd = torch.rsqrt(var + ko.BN_EPSILON)
+            sc_ref = (g64 * invstd).detach()
+            sh_ref = (b64 - mean * g64 * invstd).detach()
+            m = dict(dz_l2=_rel_l2(rows_view(dz, ld_dz), z64.grad), dgamma_l2=_rel_l2(_f64(dgamma), g64.grad),
+                     dbeta_l2=_rel_l2(_f64(dbeta), b64.grad), scale_max=_rel_max(_f64(scale), sc_ref),
+                     shift_max=float((_f64(shift) - sh_ref).abs().max())
+                     / (float(sh_ref.abs().max()) + float((mean.detach() * sc_ref).abs().max()) + 1e-300))
+            if dm is not None:
+                got = rows_view(dm, ld_dm)
+                if dm_before is not None:
+                    got = got - rows_view(dm_before, ld_dm)
+                m["shortcut_l2"] = _rel_l2(got, up)
+            self.cpu_s += time.time() - t0
+            self._note("bn", key[1:], **m)
+        return run
+
+
+def test_every_distinct_launch_of_the_benched_step_matches_the_oracle(cuda, monkeypatch):
+    assert os.environ.get("DJ_AUTOTUNE") == "table", "the registered (tile variant, split-K) choices must be the ones that run"
+    from jpeg_detection_resnet_ssd_amd import engine, workloads
+    from jpeg_detection_resnet_ssd_amd import kernels as Kn
+    from jpeg_detection_resnet_ssd_amd.keras import layers as L
+    from test_ssd_gpu import perturb_weights
+    model, sizes = workloads.build_ssd(ARCHI)
+    perturb_weights(model)
+    x, y = workloads.synthetic_batch(ARCHI, sizes, BATCH, fast=True)
+    plan = model._plan(BATCH, True, True)
+    # the table must really cover the plan: an untuned geometry would run the launcher's default instead
+    names = [n for n, _ in type(plan.conv_calls[0][1])._fields_][:15]
+    missing = [d for d, desc, _ in plan.conv_calls
+               if (d,) + tuple(getattr(desc, n) for n in names) not in engine._TUNED]
+    assert not missing, "%d conv launches of the benched plan have no entry in the tuning table" % len(missing)
+    model._upload(plan, x, y)
+    plan.run_forward()           # warm pass (moving statistics, lazy module loads) without the recorder
+    plan.run_backward()
+    torch.cuda.synchronize()
+
+    rp = Replay()
+    for lyr in model.layers:
+        if isinstance(lyr, L.BatchNormalization):
+            rp.bn_params[lyr.gamma.param.data_ptr()] = (lyr.gamma.param, lyr.beta.param, lyr.epsilon)
+            assert lyr.epsilon == ko.BN_EPSILON
+    monkeypatch.setattr(Kn, "conv2d_fwd", rp.fwd(Kn.conv2d_fwd))
+    monkeypatch.setattr(Kn, "conv2d_fwd_addrelu", rp.fwd_addrelu(Kn.conv2d_fwd_addrelu))
+    monkeypatch.setattr(Kn, "conv2d_dgrad", rp.dgrad(Kn.conv2d_dgrad))
+    monkeypatch.setattr(Kn, "conv2d_wgrad", rp.wgrad(Kn.conv2d_wgrad))
+    monkeypatch.setattr(L, "call", rp.call(L.call))
+    t0 = time.time()
+    plan.run_forward()
+    plan.run_backward()
+    torch.cuda.synchronize()
+    wall = time.time() - t0
+
+    kinds = {}
+    for kind, geom, metric, value in rp.rows:
+        kinds.setdefault((kind, metric), []).append((value, geom))
+    print("\nreplayed %d distinct launches of the %s B=%d step in %.0f s (oracle CPU time %.0f s)"
+          % (len(rp.seen), ARCHI, BATCH, wall, rp.cpu_s))
+    for (kind, metric), vals in sorted(kinds.items()):
+        worst = max(vals)
+        print("  %-12s %-12s n=%3d  median %.2e  max %.2e  at %s"
+              % (kind, metric, len(vals), float(np.median([v for v, _ in vals])), worst[0], worst[1]))
+    n_kind = {k: sum(1 for s in rp.seen if s[0] == k) for k in ("fwd", "fwd_addrelu", "dgrad", "wgrad", "bn")}
+    # the deconv SSD300 graph: 76 convolutions + 2 transposed ones, 53 BatchNormalization layers
+    assert n_kind["fwd"] >= 25 and n_kind["dgrad"] >= 25 and n_kind["wgrad"] >= 30 and n_kind["bn"] >= 10, n_kind
+    assert n_kind["fwd_addrelu"] >= 3, n_kind
+    bad = [(kind, geom, metric, value) for kind, geom, metric, value in rp.rows if not value <= TOL]
+    assert not bad, bad[:10]

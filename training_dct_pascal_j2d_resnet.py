@@ -155,7 +155,9 @@ if rank == 0:
                   append=True)] + callbacks
 
 if args.restart:
-    initial_epoch = int(args.restart.split("-")[1].split("_")[0])
+    # "..._epoch-{epoch:02d}_loss-..." (the ModelCheckpoint pattern above).  The reference parses the whole path
+    # (`args.restart.split('-')[1]`), which breaks on a directory name containing '-'; the file name alone is parsed here
+    initial_epoch = int(os.path.basename(args.restart).split("-")[1].split("_")[0])
 else:
     initial_epoch = 0
 history = model.fit_generator(generator=train_generator, steps_per_epoch=args.steps_per_epoch, epochs=args.epochs,
