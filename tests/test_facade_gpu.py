@@ -78,7 +78,13 @@ def test_fit_generator_with_the_trainers_callbacks(cuda, tmp_path):
     assert n == len(fresh.weight_specs) == len(saved)
     probe, _ = build(ARCHI, seed=8)
     probe.set_weights_dict(saved, strict=True)
-    np.testing.assert_array_equal(fresh.predict(x, batch_size=BATCH), probe.predict(x, batch_size=BATCH))
+    # same weights, two models: the boxes of the 38x38 source sit upstream of every split-K convolution and are
+    # bit-identical; downstream of fc6 (K = 18432 split over workgroups, fp32 atomics in arrival order) two evaluations
+    # of the SAME model differ in the last bits too -- measured 1e-4 of the largest value after conv6..conv9
+    a, b = fresh.predict(x, batch_size=BATCH), probe.predict(x, batch_size=BATCH)
+    n38 = 38 * 38 * 4
+    np.testing.assert_array_equal(a[:, :n38], b[:, :n38])
+    assert np.abs(a - b).max() <= 1e-3 * np.abs(a).max()
 
     # by_name with a SUBSET of the names plus names the model does not have: Keras loads what matches, silently skips
     # the rest; by_name=False insists on every weight

@@ -51,6 +51,10 @@ def _oracle_conv(a, w, bias, desc):
     return ko.conv2d(a, w, bias, (desc.stride_h, desc.stride_w), "valid", (desc.dilation_h, desc.dilation_w))
 
 
+def invstd_of(var):
+    return torch.rsqrt(var + ko.BN_EPSILON)
+
+
 def _rel_l2(got, ref):
     return float((got - ref).norm()) / (float(ref.norm()) + 1e-300)
 
@@ -228,10 +232,25 @@ class Replay(object):
             invstd = torch.rsqrt(var + ko.BN_EPSILON)
             sc_ref = (g64 * invstd).detach()
             sh_ref = (b64 - mean * g64 * invstd).detach()
-            m = dict(dz_l2=_rel_l2(rows_view(dz, ld_dz), z64.grad), dgamma_l2=_rel_l2(_f64(dgamma), g64.grad),
-                     dbeta_l2=_rel_l2(_f64(dbeta), b64.grad), scale_max=_rel_max(_f64(scale), sc_ref),
+            # dgamma / dbeta are column sums over `rows` pixels and may cancel -- for a BatchNormalization whose consumers
+            # are 1x1 convolutions followed by another BatchNormalization (the input BN of this graph) dbeta is
+            # ANALYTICALLY zero and both sides hold rounding noise -- so they are measured against the natural scale of
+            # such a sum, sqrt(rows) * ||column||_2, and additionally as a relative L2 error when the reference is not
+            # itself at the noise level of that scale
+            n_rows = float(int(rows))
+            xhat = ((z64 - mean) * invstd_of(var)).detach()
+            nat_b = (n_rows ** 0.5) * up.norm(dim=0).clamp_min(1e-300)
+            nat_g = (n_rows ** 0.5) * (up * xhat).norm(dim=0).clamp_min(1e-300)
+            m = dict(dz_l2=_rel_l2(rows_view(dz, ld_dz), z64.grad),
+                     dgamma_nat=float(((_f64(dgamma) - g64.grad).abs() / nat_g).max()),
+                     dbeta_nat=float(((_f64(dbeta) - b64.grad).abs() / nat_b).max()),
+                     scale_max=_rel_max(_f64(scale), sc_ref),
                      shift_max=float((_f64(shift) - sh_ref).abs().max())
                      / (float(sh_ref.abs().max()) + float((mean.detach() * sc_ref).abs().max()) + 1e-300))
+            if float(g64.grad.norm()) > 1e-4 * float(nat_g.norm()):
+                m["dgamma_l2"] = _rel_l2(_f64(dgamma), g64.grad)
+            if float(b64.grad.norm()) > 1e-4 * float(nat_b.norm()):
+                m["dbeta_l2"] = _rel_l2(_f64(dbeta), b64.grad)
             if dm is not None:
                 got = rows_view(dm, ld_dm)
                 if dm_before is not None:
@@ -291,5 +310,7 @@ def test_every_distinct_launch_of_the_benched_step_matches_the_oracle(cuda, monk
     # the deconv SSD300 graph: 76 convolutions + 2 transposed ones, 53 BatchNormalization layers
     assert n_kind["fwd"] >= 25 and n_kind["dgrad"] >= 25 and n_kind["wgrad"] >= 30 and n_kind["bn"] >= 10, n_kind
     assert n_kind["fwd_addrelu"] >= 3, n_kind
-    bad = [(kind, geom, metric, value) for kind, geom, metric, value in rp.rows if not value <= TOL]
+    # sums measured on their natural scale: fp32 partial sums in double totals stay below 1e-6 of it
+    bad = [(kind, geom, metric, value) for kind, geom, metric, value in rp.rows
+           if not value <= (1e-5 if metric.endswith("_nat") else TOL)]
     assert not bad, bad[:10]
