@@ -11,7 +11,8 @@
 struct TileCfg {
   int bm, bn;
 };
-static const TileCfg kCfgs[] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {128, 128}, {128, 64}, {64, 64}, {64, 64}, {128, 64}, {128, 128}, {128, 64}, {64, 64}, {64, 64}, {128, 64}};
+static const TileCfg kCfgs[] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {128, 128}, {128, 64}, {64, 64}, {64, 64}, {128, 64}, {128, 128}, {128, 64}, {64, 64}, {64, 64}, {128, 64},
+                                 {128, 64}, {128, 128}, {64, 64}, {64, 128}, {128, 32}};
 // *_S1: same tile with a single LDS stage; *_S1P: single stage with loads two K-steps ahead; *_P: two stages with
 // the pinned-load / read-ahead schedule (fast kernel only; the generic kernel ignores the distinction)
 enum {
@@ -29,8 +30,19 @@ enum {
   CFG_64x64_P,
   CFG_64x64_PK2,
   CFG_128x64_PK2,
+  // weight gradient only (dj_wgrad_direct.h): PER-WAVE tiles of the LDS-free kernel, rows interleaved by TM
+  CFG_WD_4x2,
+  CFG_WD_4x4,
+  CFG_WD_2x2,
+  CFG_WD_2x4,
+  CFG_WD_4x1,
   N_CFG
 };
+#define CFG_WD_FIRST CFG_WD_4x2
+
+// dj_conv_wd.hip: launch the LDS-free weight-gradient kernel; `splits` pixel chunks of p.kchunk pixels
+int dj_launch_wgrad_direct(int cfg, const DjIgemmParams& p, int splits, hipStream_t s);
+bool dj_wgrad_direct_ok(const DjIgemmParams& p);
 
 template <typename KernT>
 static int launch_kernel(KernT kern, int smem_bytes, int bm, int bn, const DjIgemmParams& p, int splits, hipStream_t s,
@@ -151,6 +163,7 @@ static int launch_lowp_cfg(int cfg, const DjIgemmParams& p, int splits, hipStrea
 
 template <int AM, int BMD>
 int dj_launch_cfg(int cfg, const DjIgemmParams& p, int splits, hipStream_t s) {
+  if (cfg >= CFG_WD_FIRST && cfg < N_CFG) cfg = CFG_64x64;   // a weight-gradient-only variant asked of another role
   const int fast = fast_mode<AM, BMD>(p);
   if (fast && g_dj_compute_mode != 0 && cfg >= 0 && cfg < N_CFG) {
     // A-mode 0 with B-mode 0 is the forward GEMM; everything else carries gradients

@@ -345,6 +345,8 @@ class Plan(object):
                 split_opts = sorted({1, s0.value, 2, 4})
             best = (float("inf"), c0.value, s0.value)
             for cfg in range(ncfg):
+                if not lib.dj_conv2d_tune_config_valid(direction, cfg):
+                    continue
                 for sp in split_opts:
                     check(lib.dj_conv2d_tune_set(direction, desc, cfg, sp), "tune_set")
                     fn()
