@@ -207,3 +207,180 @@ __global__ __launch_bounds__(256, (TM * TN > 8) ? 1 : 2) void dj_wgrad_direct_ke
       }
     }
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same GEMM for the geometries where everything about a pixel pair is WAVE-UNIFORM and affine in the pair index:
+// stride 1 with out size == in size (every 1x1 and every 'same' k x k convolution of the graphs) and one filter tap
+// per wave tile (in_c % (32*TM) == 0).  Measured on gfx950 (tools/micro/mfma_valu.hip): v_mfma_f32_32x32x2_f32 and the
+// vector ALU do not overlap -- every VALU instruction of a wave adds its ~5 issue cycles to the 64 of an MFMA -- while
+// scalar instructions and loads are free.  So this variant spends its per-pair work on the scalar unit:
+//   * x / dy byte offsets advance by one v_add each per pair (the per-lane parts are loop constants; the column tiles
+//     of dy use the instruction's immediate offset);
+//   * the pixel coordinates of the pair are tracked in SGPRs; for padded taps the validity of the two pixels becomes a
+//     64-bit lane mask (low half = first pixel) that one v_cndmask applies to the x offset;
+//   * the BatchNormalization(+ReLU) prologue is the only other vector work: 2 (+1 when padded) VALU per x element.
+// PAD = 0: no tap of the tile can leave the image (1x1 convolutions): no validity at all.
+// ---------------------------------------------------------------------------------------------------------------
+template <int TM, int TN, int PRO, int PAD, int U>
+__global__ __launch_bounds__(256, (TM * TN > 8) ? 1 : 2) void dj_wgrad_direct_lin_kernel(const DjIgemmParams p) {
+  typedef typename DjVecOf<TM>::type avec;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably uniform from here on
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int tiles_m = (p.M + 32 * TM - 1) / (32 * TM), tiles_n = (p.N + 32 * TN - 1) / (32 * TN);
+  const int groups = (tiles_m * tiles_n + 3) >> 2;
+  int logical;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, slot = b >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int chunk = logical / groups;
+  const int wt = (logical - chunk * groups) * 4 + wave;
+  if (wt >= tiles_m * tiles_n) return;
+  const int tile_m = wt / tiles_n, tile_n = wt - tile_m * tiles_n;
+  const int kbeg = chunk * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
+  const int npairs = (kend - kbeg + 1) >> 1;
+
+  // one tap per wave tile
+  const int m0 = tile_m * 32 * TM;
+  const int tap = m0 / p.srcC;
+  const int c0 = m0 - tap * p.srcC;
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int dh = kh * p.dH - p.pT, dw = kw * p.dW - p.pL;
+  const int ldx4 = p.ldsrc * 4, ldy4 = p.ldb * 4;
+
+  // x: the whole tensor; a lane's byte offset (first pixel of the chunk + tap shift + channel) may be negative for taps
+  // above the first image row: as an unsigned offset that is out of range, which is what such a pixel must read anyway.
+  // dy: based at this chunk's first pixel and ending with its last one, so pairs past the chunk read zeros.  Range
+  // checks see the VGPR offset + immediate only: nothing per-pair is passed through the scalar offset operand.
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.B + (long)kbeg * ldy4), 0,
+                                                                      (int)((long)(kend - kbeg) * ldy4), 0x00020000);
+
+  const int c_lane = c0 + TM * l31;
+  const bool a_ok = m0 + TM * l31 < p.M;
+  // (the x offset of a lane that has no row stays out of range for the whole chunk: 2^31 + anything a chunk adds)
+  // signed arithmetic (no wrap-around the compiler must respect): constant parts fold into the immediate offsets
+  int offA = a_ok ? (kbeg + lh + dh * p.srcW + dw) * ldx4 + c_lane * 4 : (int)0x80000000;
+  int offB = lh * ldy4 + (tile_n * 32 * TN + l31) * 4;
+  const int stepA = 2 * ldx4, stepB = 2 * ldy4;
+  avec sc, sh;
+  if (PRO) {
+    const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)p.pro_scale, 0, p.srcC * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void*)p.pro_shift, 0, p.srcC * 4, 0x00020000);
+    sc = dj_buf_ldv<TM>(rS, a_ok ? (unsigned)c_lane * 4u : DJ_WD_OOB);
+    sh = dj_buf_ldv<TM>(rT, a_ok ? (unsigned)c_lane * 4u : DJ_WD_OOB);
+  }
+  const float relu_floor = p.pro_relu ? 0.f : -INFINITY;
+
+  // scalar pixel state of the pair's FIRST pixel
+  int s_pix = kbeg, s_oh, s_ow;
+  {
+    const int hw = p.rowH * p.rowW;
+    const int img = s_pix / hw;
+    const int rem = s_pix - img * hw;
+    s_oh = rem / p.rowW;
+    s_ow = rem - s_oh * p.rowW;
+  }
+
+  struct Stage {
+    avec a[U];
+    float b[U][TN];
+    unsigned ok0, ok1;   // bit j: first / second pixel of pair j lies inside the image under this tile's tap (PAD)
+  };
+  Stage s0, s1;
+
+  auto lane_mask = [](bool ok0, bool ok1) -> unsigned long long {
+    return (ok0 ? 0x00000000FFFFFFFFull : 0ull) | (ok1 ? 0xFFFFFFFF00000000ull : 0ull);
+  };
+  auto issue = [&](Stage& S) {
+    S.ok0 = S.ok1 = 0;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      int oa = offA;
+      if (PAD) {
+        // second pixel of the pair: one step right, wrapping to the next row (out_w >= 2); selects, not branches: the
+        // loop body must stay one basic block for the MFMA / load pipeline
+        const int w1 = (s_ow + 1 >= p.rowW) ? 1 : 0;
+        const int ow1 = w1 ? 0 : s_ow + 1;
+        const int oh1 = (s_oh + w1 >= p.rowH) ? 0 : s_oh + w1;
+        const bool ok0 = ((unsigned)(s_oh + dh) < (unsigned)p.srcH) & ((unsigned)(s_ow + dw) < (unsigned)p.srcW) & (s_pix < kend);
+        const bool ok1 = ((unsigned)(oh1 + dh) < (unsigned)p.srcH) & ((unsigned)(ow1 + dw) < (unsigned)p.srcW) & (s_pix + 1 < kend);
+        S.ok0 |= ok0 ? (1u << j) : 0u;
+        S.ok1 |= ok1 ? (1u << j) : 0u;
+        asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(oa) : "v"((int)DJ_WD_OOB), "v"(offA), "s"(lane_mask(ok0, ok1)));
+        const int w2 = (s_ow + 2 >= p.rowW) ? 1 : 0;
+        s_ow = s_ow + 2 - (w2 ? p.rowW : 0);
+        s_oh = (s_oh + w2 >= p.rowH) ? 0 : s_oh + w2;
+      }
+      S.a[j] = dj_buf_ldv<TM>(rA, (unsigned)oa);
+#pragma unroll
+      for (int u = 0; u < TN; ++u) S.b[j][u] = dj_buf_ld1(rB, (unsigned)(offB + 128 * u));
+      // one vector add per operand and pair, kept opaque so that the compiler does not trade it for an induction
+      // variable per load (each of those is another VALU instruction per pair)
+      asm volatile("v_add_u32 %0, %1, %0" : "+v"(offA) : "s"(stepA));
+      asm volatile("v_add_u32 %0, %1, %0" : "+v"(offB) : "s"(stepB));
+      s_pix += 2;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int t = 0; t < TM; ++t)
+#pragma unroll
+    for (int u = 0; u < TN; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+  auto compute = [&](Stage& S) {
+    // (the validity bits are wave-uniform; said explicitly, or they travel through the loop in vector registers)
+    const unsigned k0 = PAD ? __builtin_amdgcn_readfirstlane(S.ok0) : 0u, k1 = PAD ? __builtin_amdgcn_readfirstlane(S.ok1) : 0u;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      avec a = S.a[j];
+      if (PRO) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+          float v = fmaxf(a[t] * sc[t] + sh[t], relu_floor);
+          if (PAD) asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(v) : "v"(v), "s"(lane_mask((k0 >> j) & 1u, (k1 >> j) & 1u)));
+          a[t] = v;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TN; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], S.b[j][u], acc[t][u], 0, 0, 0);
+    }
+  };
+
+  issue(s0);
+  for (int it = 0; it < npairs; it += 2 * U) {
+    issue(s1);
+    compute(s0);
+    issue(s0);
+    compute(s1);
+  }
+
+#pragma unroll
+  for (int t = 0; t < TM; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int m = m0 + TM * i + t;
+      if (m >= p.M) continue;
+      float* row = p.C + (size_t)m * p.ldc;
+#pragma unroll
+      for (int u = 0; u < TN; ++u) {
+        const int n = tile_n * 32 * TN + 32 * u + l31;
+        if (n >= p.N) continue;
+        if (p.atomic)
+          unsafeAtomicAdd(row + n, acc[t][u][r]);
+        else
+          row[n] = acc[t][u][r];
+      }
+    }
+}

@@ -162,6 +162,9 @@ VARIANT_CASES = [
     (3, 19, 19, 96, 128, 3, 1, "same", 1),      # K = 27 K-steps (odd: the K groups of the *_PK2 variants get 14 / 13)
     (2, 10, 10, 64, 192, 1, 1, "valid", 1),     # K = 2 K-steps, N = 1.5 tiles of 128
     (2, 38, 38, 32, 64, 2, 1, "same", 1),       # one K-step per tap (srcC = 32), asymmetric padding
+    (3, 19, 19, 128, 96, 3, 1, "same", 1),      # LDS-free wgrad, scalar-addressed form: one tap per wave tile, odd pixel count
+    (3, 19, 19, 256, 40, 3, 1, "same", 2),      # ... dilation 2, N not a multiple of 32
+    (5, 7, 9, 128, 64, 1, 1, "valid", 1),       # ... 1x1 (no padding tests), 315 pixels
 ]
 
 

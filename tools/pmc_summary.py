@@ -1,8 +1,10 @@
 """Summarise a rocprofv3 --pmc run of tools/one_conv.py: per igemm kernel, last dispatch."""
 import csv, sys, glob, collections
 for d in sys.argv[1:]:
+    if not glob.glob(d + "/*/*_counter_collection.csv"):
+        continue
     f = glob.glob(d + "/*/*_counter_collection.csv")[0]
-    rows = [r for r in csv.DictReader(open(f)) if "dj_igemm" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if "dj_igemm" in r["Kernel_Name"] or "dj_wgrad" in r["Kernel_Name"]]
     last = max(int(r["Dispatch_Id"]) for r in rows)
     c = {r["Counter_Name"]: float(r["Counter_Value"]) for r in rows if int(r["Dispatch_Id"]) == last}
     r0 = [r for r in rows if int(r["Dispatch_Id"]) == last][0]
