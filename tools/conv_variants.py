@@ -1,5 +1,5 @@
-"""Weight-gradient GEMM: every tile variant x split factor on the wgrad geometries of the bench plan (or a few named
-ones), checked against the first variant's result.   python tools/wgrad_bench.py [all]"""
+"""One conv direction (fwd | dgrad | wgrad): every tile variant x split factor on representative geometries of the bench
+plan, each checked against the first variant's result.   python tools/conv_variants.py dgrad"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -24,8 +24,9 @@ SHAPES = [  # name, B,H,W,Cin,Cout,k,s,pad,dil
 lib = _lib.load()
 dev = torch.device("cuda:0")
 ncfg = lib.dj_conv2d_tune_configs()
+DIR = {"fwd": 0, "dgrad": 1, "wgrad": 2}[sys.argv[1] if len(sys.argv) > 1 else "wgrad"]
 names = ["128x128", "128x64", "64x64", "128x32", "128x128_S1", "128x64_S1", "64x64_S1", "64x64_S1P", "128x64_S1P", "128x128_P",
-         "128x64_P", "64x64_P", "64x64_PK2", "128x64_PK2", "WD_4x2", "WD_4x4", "WD_2x2", "WD_2x4", "WD_4x1"]
+         "128x64_P", "64x64_P", "64x64_PK2", "128x64_PK2", "WD_4x2", "WD_4x4", "WD_2x2", "WD_2x4", "WD_4x1", "DD_2x2", "DD_2x4", "DD_4x2", "DD_4x4", "DD_1x2"]
 
 
 def timeit(fn, iters=6):
@@ -36,36 +37,50 @@ def timeit(fn, iters=6):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
 
-only_wd = len(sys.argv) > 1 and sys.argv[1] == "wd"
 for name, b, h, w, ci, co, k, s, pad, d in SHAPES:
     desc = K.make_conv_desc(b, h, w, ci, co, (k, k), (s, s), pad, (d, d))
     x = torch.randn(b, h, w, ci, device=dev)
     dy = torch.randn(b, desc.out_h, desc.out_w, co, device=dev)
     sc, sh = torch.rand(ci, device=dev) + 0.5, torch.randn(ci, device=dev)
     dw = torch.zeros(k, k, ci, co, device=dev)
+    wt = torch.randn(k, k, ci, co, device=dev) * 0.05
+    dx = torch.zeros(b, h, w, ci, device=dev)
+    y = torch.zeros(b, desc.out_h, desc.out_w, co, device=dev)
     flop = 2.0 * b * desc.out_h * desc.out_w * co * k * k * ci
     kk = b * desc.out_h * desc.out_w
     ref, rows = None, []
     for cfg in range(ncfg):
-        if not lib.dj_conv2d_tune_config_valid(2, cfg):
+        if not lib.dj_conv2d_tune_config_valid(DIR, cfg):
             continue
-        for sp in (1, 2, 4, 7, 14, 28, 56):
-            if sp > 1 and kk // sp < 256:
+        direct = names[cfg].startswith("DD")
+        for sp in ((1, 2, 4, 7, 14, 28, 56) if DIR == 2 else ((1,) if direct else (1, 2, 4))):
+            if DIR == 2 and sp > 1 and kk // sp < 256:
                 continue
-            _lib.check(lib.dj_conv2d_tune_set(2, desc, cfg, sp), "tune_set")
-            fn = lambda: K.conv2d_wgrad(desc, x, dy, dw, sc, sh, True)
+            if DIR != 2 and sp > 1 and (k * k * (co if DIR == 1 else ci)) // sp < 256:
+                continue
+            _lib.check(lib.dj_conv2d_tune_set(DIR, desc, cfg, sp), "tune_set")
+            if DIR == 2:
+                fn = lambda: K.conv2d_wgrad(desc, x, dy, dw, sc, sh, True)
+                out = dw
+            elif DIR == 1:
+                fn = lambda: K.conv2d_dgrad(desc, dy, wt, dx)
+                out = dx
+            else:
+                fn = lambda: K.conv2d_fwd(desc, x, wt, None, y, sc, sh, True)
+                out = y
             t = timeit(fn)
-            got = dw.clone()
+            got = out.clone()
             if ref is None:
                 ref = got
             err = float((got - ref).abs().max() / ref.abs().max())
             rows.append((t, names[cfg], sp, err))
     rows.sort()
-    best_old = min(r for r in rows if not r[1].startswith("WD"))
-    best_new = min(r for r in rows if r[1].startswith("WD"))
+    best_old = min(r for r in rows if not r[1][:2] in ("WD", "DD"))
+    new = [r for r in rows if r[1][:2] in ("WD", "DD")]
+    best_new = min(new) if new else (float("nan"), "-", 0, 0.0)
     print("%-26s %6.1f GFLOP | old best %-11s sp %2d %7.3f ms %6.1f TF | direct best %-7s sp %2d %7.3f ms %6.1f TF | max err %.1e"
           % (name, flop / 1e9, best_old[1], best_old[2], best_old[0], flop / best_old[0] / 1e9, best_new[1], best_new[2],
              best_new[0], flop / best_new[0] / 1e9, max(r[3] for r in rows)), flush=True)
     for t, n, sp, err in rows[:6]:
         print("      %-11s sp %2d %7.3f ms %6.1f TF err %.1e" % (n, sp, t, flop / t / 1e9, err))
-    _lib.check(lib.dj_conv2d_tune_set(2, desc, -1, 1), "tune_set")
+    _lib.check(lib.dj_conv2d_tune_set(DIR, desc, -1, 1), "tune_set")

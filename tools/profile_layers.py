@@ -22,6 +22,7 @@ def wrap(name):
         return r
     setattr(Kn, name, timed)
 for n in ("conv2d_fwd", "conv2d_fwd_addrelu", "conv2d_dgrad", "conv2d_wgrad"): wrap(n)
+plan.side_enabled = False      # one stream: an event pair brackets its launch alone
 model.run_train_step(plan); torch.cuda.synchronize()
 agg = collections.OrderedDict()
 for name, key, e0, e1, fl in recs:
