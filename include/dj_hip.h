@@ -124,9 +124,6 @@ int dj_get_compute_mode(void);
  * 2 wgrad (+4: forward that takes BN statistics); cfg in [0, dj_conv2d_tune_configs()) selects the tile shape
  * (128x128, 128x64, 64x64, 128x32), `splits` the split-K factor; cfg < 0 removes the override. */
 int dj_conv2d_tune_configs(void);
-/* 1 when variant `cfg` exists for `dir` (the LDS-free per-wave tiles 4x2 / 4x4 / 2x2 / 2x4 / 4x1 of the weight-gradient
- * GEMM are dir 2 only; asked of another direction they run the 64x64 tile). */
-int dj_conv2d_tune_config_valid(int dir, int cfg);
 int dj_conv2d_tune_set(int dir, const dj_conv2d_desc* d, int cfg, int splits);
 int dj_conv2d_default_config(int dir, const dj_conv2d_desc* d, int* cfg, int* splits);
 

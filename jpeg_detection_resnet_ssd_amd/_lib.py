@@ -80,7 +80,6 @@ SIGNATURES = {
     "dj_set_compute_mode": (c_int, [c_int]),
     "dj_get_compute_mode": (c_int, []),
     "dj_conv2d_tune_configs": (c_int, []),
-    "dj_conv2d_tune_config_valid": (c_int, [c_int, c_int]),
     "dj_conv2d_tune_set": (c_int, [c_int, POINTER(ConvDesc), c_int, c_int]),
     "dj_conv2d_default_config": (c_int, [c_int, POINTER(ConvDesc), POINTER(c_int), POINTER(c_int)]),
     "dj_reduce_rows": (c_int, [c_long]),

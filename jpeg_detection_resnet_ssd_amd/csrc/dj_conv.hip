@@ -415,11 +415,6 @@ extern "C" int dj_conv2d_nhwc_dgrad(const dj_conv2d_desc* d, const float* dy, co
   p.cmap = 0;
   int cfg = choose_cfg(p.M, p.N, p.K, true, &splits);
   tune_lookup(1, d, &cfg, &splits);
-  if (cfg >= CFG_DD_FIRST && cfg < N_CFG) {
-    // LDS-free kernel: whole K per wave (no split), plain or accumulating stores
-    if (g_dj_compute_mode == 0 && dj_dgrad_direct_ok(p)) return dj_launch_dgrad_direct(cfg, p, s);
-    cfg = choose_cfg(p.M, p.N, p.K, true, &splits);
-  }
   p.kchunk = dj_cdiv(dj_cdiv(p.K, splits), DJ_BK) * DJ_BK;
   splits = dj_cdiv(p.K, p.kchunk);
   if (splits > 1) {
@@ -487,11 +482,6 @@ extern "C" int dj_conv2d_nhwc_wgrad(const dj_conv2d_desc* d, const float* x, con
   splits = (int)(want < maxs ? want : maxs);
   if (splits < 1) splits = 1;
   tune_lookup(2, d, &cfg, &splits);
-  const bool direct = cfg >= CFG_WD_FIRST && cfg < CFG_DD_FIRST && dj_wgrad_direct_ok(p) && g_dj_compute_mode == 0;
-  if (cfg >= CFG_WD_FIRST && !direct) {   // registered for a geometry / alignment the LDS-free kernel cannot take
-    cfg = (p.N > 32) ? ((p.M >= 128) ? CFG_128x64 : CFG_64x64) : CFG_128x32;
-  }
-  // pixels per chunk: a multiple of the K-step (LDS kernels) / of one pipeline stage of pixel pairs (direct kernel)
   p.kchunk = dj_cdiv(dj_cdiv(p.K, splits), DJ_BK) * DJ_BK;
   splits = dj_cdiv(p.K, p.kchunk);
   if (splits > 1) {
@@ -504,17 +494,7 @@ extern "C" int dj_conv2d_nhwc_wgrad(const dj_conv2d_desc* d, const float* x, con
       }
     }
   }
-  if (direct) return dj_launch_wgrad_direct(cfg, p, splits, s);
   return dj_launch_cfg<2, 0>(cfg, p, splits, s);
-}
-
-// 1 when tile variant `cfg` exists for direction `dir` (0 fwd, 1 dgrad, 2 wgrad, +4 forward with BN statistics):
-// the tuner's candidate list
-extern "C" int dj_conv2d_tune_config_valid(int dir, int cfg) {
-  if (cfg < 0 || cfg >= N_CFG) return 0;
-  if (cfg >= CFG_DD_FIRST) return (dir & 3) == 1;
-  if (cfg >= CFG_WD_FIRST) return (dir & 3) == 2;
-  return 1;
 }
 
 extern "C" int dj_conv2d_default_config(int dir, const dj_conv2d_desc* d, int* cfg, int* splits) {

@@ -11,9 +11,7 @@
 struct TileCfg {
   int bm, bn;
 };
-static const TileCfg kCfgs[] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {128, 128}, {128, 64}, {64, 64}, {64, 64}, {128, 64}, {128, 128}, {128, 64}, {64, 64}, {64, 64}, {128, 64},
-                                 {128, 64}, {128, 128}, {64, 64}, {64, 128}, {128, 32},
-                                 {64, 64}, {64, 128}, {128, 64}, {128, 128}, {32, 64}};
+static const TileCfg kCfgs[] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {128, 128}, {128, 64}, {64, 64}, {64, 64}, {128, 64}, {128, 128}, {128, 64}, {64, 64}, {64, 64}, {128, 64}};
 // *_S1: same tile with a single LDS stage; *_S1P: single stage with loads two K-steps ahead; *_P: two stages with
 // the pinned-load / read-ahead schedule (fast kernel only; the generic kernel ignores the distinction)
 enum {
@@ -31,29 +29,8 @@ enum {
   CFG_64x64_P,
   CFG_64x64_PK2,
   CFG_128x64_PK2,
-  // weight gradient only (dj_wgrad_direct.h): PER-WAVE tiles of the LDS-free kernel, rows interleaved by TM
-  CFG_WD_4x2,
-  CFG_WD_4x4,
-  CFG_WD_2x2,
-  CFG_WD_2x4,
-  CFG_WD_4x1,
-  // input gradient only (dj_dgrad_direct.h): per-wave tiles of the LDS-free kernel
-  CFG_DD_2x2,
-  CFG_DD_2x4,
-  CFG_DD_4x2,
-  CFG_DD_4x4,
-  CFG_DD_1x2,
   N_CFG
 };
-#define CFG_WD_FIRST CFG_WD_4x2
-#define CFG_DD_FIRST CFG_DD_2x2
-
-int dj_launch_dgrad_direct(int cfg, const DjIgemmParams& p, hipStream_t s);
-bool dj_dgrad_direct_ok(const DjIgemmParams& p);
-
-// dj_conv_wd.hip: launch the LDS-free weight-gradient kernel; `splits` pixel chunks of p.kchunk pixels
-int dj_launch_wgrad_direct(int cfg, const DjIgemmParams& p, int splits, hipStream_t s);
-bool dj_wgrad_direct_ok(const DjIgemmParams& p);
 
 template <typename KernT>
 static int launch_kernel(KernT kern, int smem_bytes, int bm, int bn, const DjIgemmParams& p, int splits, hipStream_t s,
@@ -174,7 +151,6 @@ static int launch_lowp_cfg(int cfg, const DjIgemmParams& p, int splits, hipStrea
 
 template <int AM, int BMD>
 int dj_launch_cfg(int cfg, const DjIgemmParams& p, int splits, hipStream_t s) {
-  if (cfg >= CFG_WD_FIRST && cfg < N_CFG) cfg = CFG_64x64;   // a single-role (LDS-free) variant asked of another role
   const int fast = fast_mode<AM, BMD>(p);
   if (fast && g_dj_compute_mode != 0 && cfg >= 0 && cfg < N_CFG) {
     // A-mode 0 with B-mode 0 is the forward GEMM; everything else carries gradients

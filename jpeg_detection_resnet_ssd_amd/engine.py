@@ -319,20 +319,6 @@ class Plan(object):
             if key in _TUNED:
                 continue
             known = _tune_db().get(",".join(str(int(v)) for v in key))
-            force = os.environ.get("DJ_FORCE_VARIANT_%d" % (direction & 3))     # experiments: "cfg[,waves]"
-            if force:
-                parts = [int(v) for v in force.split(",")]
-                cfg_f, waves = parts[0], (parts[1] if len(parts) > 1 else 2048)
-                tm_tn = {14: (4, 2), 15: (4, 4), 16: (2, 2), 17: (2, 4), 18: (4, 1)}.get(cfg_f)
-                sp = 1
-                if tm_tn and (direction & 3) == 2:
-                    m_, n_ = desc.kernel_h * desc.kernel_w * desc.in_c, desc.out_c
-                    tiles = -(-m_ // (32 * tm_tn[0])) * -(-n_ // (32 * tm_tn[1]))
-                    kk = desc.batch * desc.out_h * desc.out_w
-                    sp = max(1, min(waves // max(1, tiles), kk // 128))
-                check(lib.dj_conv2d_tune_set(direction, desc, cfg_f, sp), "tune_set")
-                _TUNED[key] = (0.0, cfg_f, sp)
-                continue
             if known is not None and known[0] < ncfg:
                 sp = int(known[1])
                 if len(known) > 3 and known[3]:
@@ -359,8 +345,6 @@ class Plan(object):
                 split_opts = sorted({1, s0.value, 2, 4})
             best = (float("inf"), c0.value, s0.value)
             for cfg in range(ncfg):
-                if not lib.dj_conv2d_tune_config_valid(direction, cfg):
-                    continue
                 for sp in split_opts:
                     check(lib.dj_conv2d_tune_set(direction, desc, cfg, sp), "tune_set")
                     fn()
