@@ -25,7 +25,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 25
 
 
 def conv_flops(desc):
-    return 2.0 * desc.batch * desc.out_h * desc.out_w * desc.out_c * desc.kernel_h * desc.kernel_w * desc.in_c
+    out_c = getattr(desc, "algorithmic_out_c", desc.out_c)     # fused predictor heads run on a zero-padded filter bank
+    return 2.0 * desc.batch * desc.out_h * desc.out_w * out_c * desc.kernel_h * desc.kernel_w * desc.in_c
 
 
 def measure_conv_kernels(model, plan):

@@ -209,6 +209,7 @@ class Plan(object):
         self.grad_ready = {}   # weight key -> index in self.bwd after which its gradient is final
         self.deferred_colsums = []   # (dy, rows, c, ld, grad buffer, weight spec): see build_backward
         self.conv_calls = []   # (direction, ConvDesc, launch closure) of every implicit-GEMM call, for autotune()
+        self.fused_outputs = {}   # id(Conv2D layer) -> Value, for layers lowered inside a sibling's fused GEMM
         self.grads_cleared = False   # True: the first backward launch zeroes the model's whole flat gradient buffer
         # weight-gradient GEMMs only feed the optimizer, so they run on a second HIP stream and fill the CUs the
         # data-gradient chain leaves idle at its tile-quantisation tails (DJ_SIDE_WGRAD=0 keeps one stream)

@@ -260,8 +260,114 @@ class Conv2D(Layer):
         _, _, oh, ow = Kn.conv_geometry(h, w, self.kernel_size, self.strides, self.padding, self.dilation_rate)
         return (input_shape[0], oh, ow, self.filters)
 
+    def _fusable_siblings(self, model, x):
+        """The Conv2D layers that read the same tensor with the same geometry and feed neither an activation nor a
+        BatchNormalization -- the conf / loc predictor pair of an SSD source
+        (localisation_part/models/keras_ssd300_dct_j2d_resnet.py:562-675): candidates for ONE GEMM over the
+        concatenated, zero-padded filter bank."""
+        if os.environ.get("DJ_FUSE_HEADS", "1") == "0" or x.is_affine or x.pad is not None:
+            return [self]
+        if getattr(x, "pending_add", None) is not None:
+            return [self]
+        sibs = []
+        for lyr in model.consumers_of(self.inbound[0]):
+            if type(lyr) is not Conv2D or lyr.activation is not None or lyr.bias is None:
+                continue
+            if (lyr.kernel_size, lyr.strides, lyr.padding, lyr.dilation_rate) != (
+                    self.kernel_size, self.strides, self.padding, self.dilation_rate):
+                continue
+            users = model.consumers_of(lyr.outbound[0])
+            if any(isinstance(u, (BatchNormalization, Activation)) for u in users):
+                continue
+            sibs.append(lyr)
+        sibs.sort(key=lambda l: l.serial)
+        # worth it when a member cannot take the branch-free kernel by itself (rows of 126 / 84 floats) or is too narrow
+        # to fill a column tile
+        if len(sibs) < 2 or self not in sibs or not any(l.filters % 32 for l in sibs):
+            return [self]
+        return sibs
+
+    def _lower_fused(self, plan, model, x, sibs):
+        """One forward GEMM, one input-gradient GEMM and one weight-gradient GEMM for all of `sibs`: their kernels are
+        packed side by side into Wp[kh, kw, Cin, Np] (Np = total filters rounded up to 32, padding columns zero) by one
+        multi-part copy per step, the outputs / output gradients travel through (B, OH, OW, Np) buffers, and the
+        Keras-named kernels, biases and their gradients stay where the optimizer and the checkpoints expect them."""
+        b, h, w, cin = x.buf.shape
+        n_tot = sum(l.filters for l in sibs)
+        n_pad = (n_tot + 31) // 32 * 32
+        desc = Kn.make_conv_desc(b, h, w, cin, n_pad, self.kernel_size, self.strides, self.padding, self.dilation_rate)
+        desc.algorithmic_out_c = n_tot       # what FLOP accounting may count (bench.py): padding columns are not work
+        kh, kw = self.kernel_size
+        krows = kh * kw * cin
+        rows = b * desc.out_h * desc.out_w
+        wp = plan.zeros(kh, kw, cin, n_pad)
+        bias_p = plan.zeros(n_pad)
+        wp2, offs, o = wp.view(krows, n_pad), [], 0
+        for l in sibs:
+            offs.append(o)
+            o += l.filters
+        pack_parts = []
+        for l, off in zip(sibs, offs):
+            pack_parts.append((l.kernel.param.view(krows, l.filters), l.filters, wp2[:, off:off + l.filters], n_pad, krows,
+                               l.filters, 0))
+            pack_parts.append((l.bias.param.view(1, l.filters), l.filters, bias_p.view(1, n_pad)[:, off:off + l.filters],
+                               n_pad, 1, l.filters, 0))
+        plan.emit(engine.copy2d_multi(pack_parts))
+        y_zeroed = (engine.tuned_splits(0, desc) or 1) > 1 and os.environ.get("DJ_ZERO_ARENA", "1") != "0"
+        y_p = (plan.zeroed_each_step if y_zeroed else plan.empty)(b, desc.out_h, desc.out_w, n_pad)
+        xbuf = x.buf
+        plan.emit_conv(0, desc, lambda: Kn.conv2d_fwd(desc, xbuf, wp, bias_p, y_p, None, None, False, False, None, y_zeroed))
+        y_p2 = y_p.view(rows, n_pad)
+        outs, unpack = [], []
+        for l, off in zip(sibs, offs):
+            y = plan.empty(b, desc.out_h, desc.out_w, l.filters)
+            unpack.append((y_p2[:, off:off + l.filters], n_pad, y.view(rows, l.filters), l.filters, rows, l.filters, 0))
+            v = Value(y, needs_grad=True, name=l.name)
+            outs.append(v)
+            plan.fused_outputs[id(l)] = v
+        plan.emit(engine.copy2d_multi(unpack))
+
+        def build_backward():
+            live = [(l, off, v) for l, off, v in zip(sibs, offs, outs) if v.grad is not None]
+            if not live:
+                return
+            dy_p = plan.zeros(b, desc.out_h, desc.out_w, n_pad)     # columns nobody writes (padding, dead members) stay zero
+            dy_p2, pack = dy_p.view(rows, n_pad), []
+            for l, off, v in live:
+                assert v.grad.mask_y is None
+                dy = v.grad.buf
+                pack.append((dy.view(rows, l.filters), l.filters, dy_p2[:, off:off + l.filters], n_pad, rows, l.filters, 0))
+                if l.bias.trainable:
+                    _bias_grad(plan, dy, l.bias)
+            plan.emit_bwd(engine.copy2d_multi(pack))
+            train = [(l, off) for l, off, _ in live if l.kernel.trainable]
+            if train:
+                dwp = plan.zeroed_each_step(kh, kw, cin, n_pad)
+                dwp2 = dwp.view(krows, n_pad)
+                split = engine.copy2d_multi([(dwp2[:, off:off + l.filters], n_pad, l.kernel.grad.view(krows, l.filters),
+                                              l.filters, krows, l.filters, 0) for l, off in train])
+
+                def wgrad():
+                    Kn.conv2d_wgrad(desc, xbuf, dy_p, dwp, dw_zeroed=True)
+                    split()          # same stream, right behind the GEMM
+                plan.emit_conv(2, desc, wgrad, backward=True, side=True)
+                for l, _ in train:
+                    plan.note_grad(l.kernel)
+            if x.needs_grad:
+                own_memset = (engine.tuned_splits(1, desc) or 1) > 1
+                dx, beta = plan.grad_of(x, zeroed=own_memset and os.environ.get("DJ_ZERO_ARENA", "1") != "0")
+                plan.emit_conv(1, desc, lambda: Kn.conv2d_dgrad(desc, dy_p, wp, dx, None, bool(beta)), backward=True)
+
+        plan.on_backward(build_backward)
+        return plan.fused_outputs[id(self)]
+
     def lower(self, plan, model, ins):
         x = ins[0]
+        if id(self) in plan.fused_outputs:          # lowered together with an earlier sibling
+            return plan.fused_outputs[id(self)]
+        sibs = self._fusable_siblings(model, x)
+        if len(sibs) > 1:
+            return self._lower_fused(plan, model, x, sibs)
         b, h, w, cin = x.buf.shape
         padding = self.padding
         if x.pad is not None:
