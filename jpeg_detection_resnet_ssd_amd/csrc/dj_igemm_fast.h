@@ -92,12 +92,15 @@ __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmPa
 
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)p.pro_scale, 0, PRO ? p.srcC * 4 : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void*)p.pro_shift, 0, PRO ? p.srcC * 4 : 0, 0x00020000);
+  // PRO 1: the per-channel arrays through buffer descriptors (one VGPR offset per load).  PRO 3 has four such arrays and
+  // would keep eight 4-SGPR descriptors live in the K-loop: its variants spilled 35-56 SGPRs into vector lanes
+  // (v_readlane / v_writelane in the loop, 36 B of scratch in two of them); there the arrays, whose channel offsets are
+  // always in range, are read by plain global loads from their uniform base pointers (2 SGPRs each): <= 10 spills, no
+  // scratch.  (For PRO 1 the plain loads cost more vector instructions than they save: 26.34 -> 26.46 ms per step.)
+  const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)p.pro_scale, 0, PRO == 1 ? p.srcC * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void*)p.pro_shift, 0, PRO == 1 ? p.srcC * 4 : 0, 0x00020000);
   const float relu_floor = (p.pro_relu || PRO == 3) ? 0.f : -INFINITY;
   const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A2, 0, PRO == 3 ? p.a2_bytes : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rS2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.pro_scale2, 0, (PRO == 3 && p.pro_scale2) ? p.srcC * 4 : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rT2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.pro_shift2, 0, (PRO == 3 && p.pro_scale2) ? p.srcC * 4 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)p.sum_out, 0, (PRO == 3 && p.sum_out) ? p.sum_bytes : 0, 0x00020000);
   const bool store_sum = (PRO == 3) && p.sum_out != nullptr && tile_n == 0;
 
@@ -209,16 +212,21 @@ __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmPa
       const int dh = t_kh * p.dH, dw = t_kw * p.dW;
       const int delta = (AM == 0) ? ((dh * p.srcW + dw) * p.ldsrc + t_c0) * 4 : (-(dh * p.srcW + dw) * p.ldsrc + t_c0) * 4;
       if (PRO) {
-        psc = dj_buf_ld4(rS, (unsigned)(t_c0 + 4 * ac) * 4u);
-        psh = dj_buf_ld4(rT, (unsigned)(t_c0 + 4 * ac) * 4u);
+        if (PRO == 3) {
+          psc = dj_ld4(p.pro_scale + (t_c0 + 4 * ac));
+          psh = dj_ld4(p.pro_shift + (t_c0 + 4 * ac));
+        } else {
+          psc = dj_buf_ld4(rS, (unsigned)(t_c0 + 4 * ac) * 4u);
+          psh = dj_buf_ld4(rT, (unsigned)(t_c0 + 4 * ac) * 4u);
+        }
       }
       if (PRO == 3) {
         R.c0 = t_c0;
         R.psc2 = f32x4{1.f, 1.f, 1.f, 1.f};
         R.psh2 = f32x4{0.f, 0.f, 0.f, 0.f};
         if (p.pro_scale2) {
-          R.psc2 = dj_buf_ld4(rS2, (unsigned)(t_c0 + 4 * ac) * 4u);
-          R.psh2 = dj_buf_ld4(rT2, (unsigned)(t_c0 + 4 * ac) * 4u);
+          R.psc2 = dj_ld4(p.pro_scale2 + (t_c0 + 4 * ac));
+          R.psh2 = dj_ld4(p.pro_shift2 + (t_c0 + 4 * ac));
         }
       }
       a_valid = 0;
