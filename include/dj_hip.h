@@ -12,8 +12,16 @@
  *     kernels HWIO (the Keras layout), Conv2DTranspose kernels (kh,kw,out,in);
  *   - `ld_*` = floats between consecutive pixels (>= channels: lets a tensor be a
  *     channel slice of a wider concat buffer);
- *   - `stream` is a hipStream_t passed as void*; nothing here allocates, synchronises
- *     or touches global state, so calls are capturable in a hipGraph;
+ *   - `stream` is a hipStream_t passed as void*; nothing here allocates or synchronises, so
+ *     calls are capturable in a hipGraph;
+ *   - state: every launch is a function of its arguments and of THREE library settings, all
+ *     safe to read and write from any thread and none of them touched by a compute call:
+ *     the arithmetic mode (a process default, dj_set_compute_mode, that a thread overrides
+ *     for its own launches with dj_set_thread_compute_mode -- two models of different modes,
+ *     or two threads, do not disturb each other), the per-geometry launch overrides of the
+ *     autotuner (dj_conv2d_tune_set: a mutex-guarded table keyed by geometry AND arithmetic
+ *     mode; an entry only selects among kernels that compute the same result), and the test
+ *     switch dj_set_fast_path.  The last error text (dj_last_error) is per thread;
  *   - return 0 on success, <0 on error (message: dj_last_error()); never throws.
  */
 #ifndef DJ_HIP_H
@@ -116,8 +124,11 @@ void dj_set_fast_path(int enable);
  * parity claim at 1e-3 refers to); 1 = forward GEMMs round both operands to fp16 and gradient GEMMs (dgrad, wgrad,
  * Conv2DTranspose forward) to bf16 as the fragments leave LDS, v_mfma_f32_32x32x8_{f16,bf16} with fp32 accumulation;
  * 2 = bf16 in every GEMM.  Tensors in HBM (activations, weights = the fp32 master copy, gradients, optimizer state)
- * stay fp32 in every mode.  Process-wide; returns the previous mode. */
+ * stay fp32 in every mode.  Sets the process-wide default; returns the previous default. */
 int dj_set_compute_mode(int mode);
+/* Override for the calling thread's launches (-1: follow the process default); returns the previous override.
+ * dj_get_compute_mode reports the mode the calling thread's next launch would use. */
+int dj_set_thread_compute_mode(int mode);
 int dj_get_compute_mode(void);
 
 /* Launch-configuration overrides per conv geometry, filled by the plan-time autotuner: `dir` 0 fwd, 1 dgrad,

@@ -78,6 +78,7 @@ SIGNATURES = {
                                       POINTER(BnTrain), c_void_p]),
     "dj_set_fast_path": (None, [c_int]),
     "dj_set_compute_mode": (c_int, [c_int]),
+    "dj_set_thread_compute_mode": (c_int, [c_int]),
     "dj_get_compute_mode": (c_int, []),
     "dj_conv2d_tune_configs": (c_int, []),
     "dj_conv2d_tune_set": (c_int, [c_int, POINTER(ConvDesc), c_int, c_int]),

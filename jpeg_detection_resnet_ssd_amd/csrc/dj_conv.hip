@@ -4,6 +4,7 @@
 #include <string.h>
 #include <map>
 #include <mutex>
+#include <atomic>
 #include <array>
 #include <algorithm>
 
@@ -17,18 +18,30 @@ void dj_set_error(const char* fmt, ...) {
 extern "C" const char* dj_last_error(void) { return g_err; }
 extern "C" int dj_abi_version(void) { return 1; }
 
-bool g_dj_allow_fast = true;
-extern "C" void dj_set_fast_path(int enable) { g_dj_allow_fast = enable != 0; }
+// ---- the library's only mutable state: three settings, each safe to touch from any thread ----
+// test switch: atomic, read once per launch
+std::atomic<bool> g_dj_allow_fast{true};
+extern "C" void dj_set_fast_path(int enable) { g_dj_allow_fast.store(enable != 0, std::memory_order_relaxed); }
 
-// 0: fp32 MFMA everywhere (default).  1: forward GEMMs round their operands to fp16, gradient GEMMs (dgrad, wgrad) to
-// bf16 (gradients need the exponent range); 2: bf16 everywhere.  fp32 accumulation and fp32 tensors in all modes.
-int g_dj_compute_mode = 0;
+// Arithmetic mode.  0: fp32 MFMA everywhere (default).  1: forward GEMMs round their operands to fp16, gradient GEMMs
+// (dgrad, wgrad) to bf16 (gradients need the exponent range); 2: bf16 everywhere.  fp32 accumulation and fp32 tensors in
+// all modes.  A process-wide default (atomic) that a thread can override for its own launches: a plan lowered under one
+// mode keeps running in it whatever other models or threads of the process select (engine.Plan sets the override before
+// it launches).
+static std::atomic<int> g_default_compute_mode{0};
+static thread_local int tl_compute_mode = -1;
+int dj_compute_mode() { return tl_compute_mode >= 0 ? tl_compute_mode : g_default_compute_mode.load(std::memory_order_relaxed); }
 extern "C" int dj_set_compute_mode(int mode) {
-  int prev = g_dj_compute_mode;
-  if (mode >= 0 && mode <= 2) g_dj_compute_mode = mode;
+  int prev = g_default_compute_mode.load(std::memory_order_relaxed);
+  if (mode >= 0 && mode <= 2) g_default_compute_mode.store(mode, std::memory_order_relaxed);
   return prev;
 }
-extern "C" int dj_get_compute_mode(void) { return g_dj_compute_mode; }
+extern "C" int dj_set_thread_compute_mode(int mode) {
+  int prev = tl_compute_mode;
+  if (mode >= -1 && mode <= 2) tl_compute_mode = mode;
+  return prev;
+}
+extern "C" int dj_get_compute_mode(void) { return dj_compute_mode(); }
 
 // instantiated in dj_conv_i00.hip (fwd), dj_conv_i01.hip (strided 1x1 dgrad as GEMM), dj_conv_i11.hip (dgrad),
 // dj_conv_i20.hip (wgrad)
@@ -88,8 +101,10 @@ typedef std::array<int, 16> TuneKey;
 static std::map<TuneKey, std::pair<int, int>> g_tune;
 static std::mutex g_tune_mu;
 
+// (the arithmetic mode of the calling thread is part of the key: the fp32 and the reduced-precision kernels have tables
+// of their own, and two models of different modes in one process do not overwrite each other's choices)
 static TuneKey tune_key(int dir, const dj_conv2d_desc* d) {
-  return TuneKey{dir, d->batch, d->in_h, d->in_w, d->in_c, d->out_h, d->out_w, d->out_c, d->kernel_h, d->kernel_w,
+  return TuneKey{dir | (dj_compute_mode() << 4), d->batch, d->in_h, d->in_w, d->in_c, d->out_h, d->out_w, d->out_c, d->kernel_h, d->kernel_w,
                  d->stride_h, d->stride_w, d->dilation_h, d->dilation_w, d->pad_top, d->pad_left};
 }
 

@@ -97,16 +97,17 @@ static int launch_k2(const DjIgemmParams& p, int splits, hipStream_t s, int fast
                        &done[1], 512);
 }
 
-extern bool g_dj_allow_fast;   // dj_conv.hip
+#include <atomic>
+extern std::atomic<bool> g_dj_allow_fast;   // dj_conv.hip
 
 // 0: fp32 MFMA everywhere (default).  1: forward GEMMs round their operands to fp16, gradient GEMMs (dgrad, wgrad) to
 // bf16 (gradients need the exponent range); 2: bf16 everywhere.  fp32 accumulation and fp32 tensors in all modes.
-extern int g_dj_compute_mode;   // dj_conv.hip
+int dj_compute_mode();   // dj_conv.hip: the calling thread's override, else the process default
 
 // Preconditions of dj_igemm_fast_kernel (see its header comment).
 template <int AM, int BMD>
 static int fast_mode(const DjIgemmParams& p) {
-  if (!g_dj_allow_fast || !p.vecA || !p.vecB) return 0;
+  if (!g_dj_allow_fast.load(std::memory_order_relaxed) || !p.vecA || !p.vecB) return 0;
   if (p.a_bytes <= 0 || p.b_bytes <= 0) return 0;  // operand >= 2 GiB (extent overflowed int)
   if (AM != 2 && p.srcC % 32 != 0) return 0;
   if (AM == 1 && (p.sH != 1 || p.sW != 1)) return 0;
@@ -152,10 +153,11 @@ static int launch_lowp_cfg(int cfg, const DjIgemmParams& p, int splits, hipStrea
 template <int AM, int BMD>
 int dj_launch_cfg(int cfg, const DjIgemmParams& p, int splits, hipStream_t s) {
   const int fast = fast_mode<AM, BMD>(p);
-  if (fast && g_dj_compute_mode != 0 && cfg >= 0 && cfg < N_CFG) {
+  const int mode = dj_compute_mode();
+  if (fast && mode != 0 && cfg >= 0 && cfg < N_CFG) {
     // A-mode 0 with B-mode 0 is the forward GEMM; everything else carries gradients
     const bool forward = (AM == 0 && BMD == 0);
-    if (g_dj_compute_mode == 1 && forward) return launch_lowp_cfg<AM, BMD, 1>(cfg, p, splits, s, fast);
+    if (mode == 1 && forward) return launch_lowp_cfg<AM, BMD, 1>(cfg, p, splits, s, fast);
     return launch_lowp_cfg<AM, BMD, 2>(cfg, p, splits, s, fast);
   }
   switch (cfg) {

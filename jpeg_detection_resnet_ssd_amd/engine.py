@@ -99,7 +99,36 @@ def query(name, *args):
     return check(getattr(_lib.load(), name)(*[int(a) for a in args]), name)
 
 
-_TUNED = {}   # conv geometry key -> (ms, cfg, splits), process-wide
+class _TunedByMode(dict):
+    """conv geometry key -> (ms, cfg, splits) of the choices registered with the library, one table per arithmetic mode
+    (the library keys its overrides by mode too): `_TUNED` behaves like the dict of the calling thread's current mode."""
+
+    def _cur(self):
+        return dict.setdefault(self, int(_lib.load().dj_get_compute_mode()), {})
+
+    def __contains__(self, key):
+        return key in self._cur()
+
+    def __getitem__(self, key):
+        return self._cur()[key]
+
+    def __setitem__(self, key, value):
+        self._cur()[key] = value
+
+    def __iter__(self):
+        return iter(self._cur())
+
+    def __len__(self):
+        return len(self._cur())
+
+    def items(self):
+        return self._cur().items()
+
+    def clear(self):
+        self._cur().clear()
+
+
+_TUNED = _TunedByMode()
 _TUNE_DB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gfx950_conv.json")
 _TUNE_DB_LOWP = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gfx950_conv_f16.json")
 _DB = {}      # compute mode -> {"dir,geometry...": [cfg, splits, ms]}: tile choices measured on an MI355X, shipped in-tree
@@ -125,7 +154,8 @@ def _tune_db():
 
 
 def reset_tuning():
-    """Forget the choices registered so far (the arithmetic mode changed: another table applies)."""
+    """Forget the choices registered so far for the current arithmetic mode (tests; a mode switch does not need it: the
+    library and this module keep one table per mode)."""
     lib = _lib.load()
     names = [n for n, _ in _lib.ConvDesc._fields_][:15]
     for key in list(_TUNED):
@@ -210,6 +240,9 @@ class Plan(object):
         self.deferred_colsums = []   # (dy, rows, c, ld, grad buffer, weight spec): see build_backward
         self.conv_calls = []   # (direction, ConvDesc, launch closure) of every implicit-GEMM call, for autotune()
         self.fused_outputs = {}   # id(Conv2D layer) -> Value, for layers lowered inside a sibling's fused GEMM
+        # the arithmetic mode this plan was lowered under (K.set_floatx at that time): its launches run in it whatever the
+        # process default or another plan's mode is by then (per-thread override of the C library)
+        self.compute_mode = int(_lib.load().dj_get_compute_mode()) if device.type == "cuda" else 0
         self.grads_cleared = False   # True: the first backward launch zeroes the model's whole flat gradient buffer
         # weight-gradient GEMMs only feed the optimizer, so they run on a second HIP stream and fill the CUs the
         # data-gradient chain leaves idle at its tile-quantisation tails (DJ_SIDE_WGRAD=0 keeps one stream)
@@ -415,12 +448,22 @@ class Plan(object):
 
     # ---- execution -------------------------------------------------------------
     def run_forward(self):
-        for f in self.fwd:
-            f()
+        lib = _lib.load()
+        prev = lib.dj_set_thread_compute_mode(self.compute_mode)
+        try:
+            for f in self.fwd:
+                f()
+        finally:
+            lib.dj_set_thread_compute_mode(prev)
 
     def run_backward(self):
-        for f in self.bwd:
-            f()
+        lib = _lib.load()
+        prev = lib.dj_set_thread_compute_mode(self.compute_mode)
+        try:
+            for f in self.bwd:
+                f()
+        finally:
+            lib.dj_set_thread_compute_mode(prev)
         self.join_side()
         for h in self.hooks_after_backward:
             h()

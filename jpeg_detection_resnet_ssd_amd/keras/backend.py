@@ -40,9 +40,9 @@ def set_floatx(value):
     modes = {v: k for k, v in _FLOATX.items()}
     if value not in modes:
         raise ValueError("Unknown floatx type: " + str(value))
-    if _lib.load().dj_set_compute_mode(modes[value]) != modes[value]:
-        from .. import engine
-        engine.reset_tuning()      # tile choices are per arithmetic mode (tuned/gfx950_conv.json vs ..._f16.json)
+    lib = _lib.load()
+    lib.dj_set_compute_mode(modes[value])        # process default: what models lowered from now on compute in
+    lib.dj_set_thread_compute_mode(-1)           # this thread follows it again (a plan run may have pinned its own mode)
 
 
 def get_uid(prefix=""):

@@ -244,3 +244,65 @@ def test_entry_scripts_and_tools_compile():
     assert len(files) >= 15
     for f in files:
         py_compile.compile(f, doraise=True)
+
+
+def test_library_settings_are_thread_safe_and_per_thread():
+    """include/dj_hip.h, 'state': the arithmetic mode is a process default with a per-thread override, the tuner's
+    override table is keyed by geometry AND mode and may be written from several threads at once (no GPU needed: none of
+    these entry points launches anything)."""
+    import ctypes
+    import threading
+    from jpeg_detection_resnet_ssd_amd import _lib
+    lib = _lib.load()
+    assert lib.dj_set_thread_compute_mode(-1) in (-1, 0, 1, 2)
+    assert lib.dj_set_compute_mode(0) in (0, 1, 2) and lib.dj_get_compute_mode() == 0
+    seen, errors = {}, []
+    barrier = threading.Barrier(3)
+
+    def worker(tid, mode):
+        try:
+            d = _lib.ConvDesc(4, 10, 10, 64, 10, 10, 64, 3, 3, 1, 1, 1, 1, 1, 1, 64, 64)
+            c, sp = ctypes.c_int(0), ctypes.c_int(0)
+            assert lib.dj_get_compute_mode() == 0                 # a new thread follows the process default
+            assert lib.dj_set_thread_compute_mode(mode) == -1
+            barrier.wait()
+            for i in range(3000):
+                assert lib.dj_get_compute_mode() == mode           # ... and nobody else's override leaks in
+                _lib.check(lib.dj_conv2d_tune_set(1, d, (tid + i) % 3, 1 + i % 4), "tune_set")
+                d2 = _lib.ConvDesc(4, 10, 10, 64 + 32 * (i % 5), 10, 10, 64, 3, 3, 1, 1, 1, 1, 1, 1, 64 + 32 * (i % 5), 64)
+                _lib.check(lib.dj_conv2d_tune_set(2, d2, i % 3, 1), "tune_set")
+                _lib.check(lib.dj_conv2d_default_config(0, d2, ctypes.byref(c), ctypes.byref(sp)), "default_config")
+                if i % 7 == 0:
+                    _lib.check(lib.dj_conv2d_tune_set(2, d2, -1, 1), "tune_set")
+            # a bad call's message belongs to the calling thread
+            assert lib.dj_conv2d_tune_set(0, None, 0, 1) < 0
+            seen[tid] = (lib.dj_get_compute_mode(), lib.dj_last_error().decode())
+            lib.dj_set_thread_compute_mode(-1)
+        except Exception as e:      # noqa: BLE001 -- reported by the main thread
+            errors.append((tid, repr(e)))
+            try:
+                barrier.abort()
+            except Exception:
+                pass
+
+    ts = [threading.Thread(target=worker, args=(t, m)) for t, m in ((0, 0), (1, 1), (2, 2))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    assert {k: v[0] for k, v in seen.items()} == {0: 0, 1: 1, 2: 2}
+    assert all("tune_set" in v[1] for v in seen.values())
+    assert lib.dj_get_compute_mode() == 0                            # the main thread never left the default
+    # one override table per mode: an entry registered under fp16 is not the fp32 entry of the same geometry
+    d = _lib.ConvDesc(2, 7, 7, 32, 7, 7, 32, 1, 1, 1, 1, 1, 1, 0, 0, 32, 32)
+    c, sp = ctypes.c_int(0), ctypes.c_int(0)
+    lib.dj_set_thread_compute_mode(1)
+    _lib.check(lib.dj_conv2d_tune_set(0, d, 2, 1), "tune_set")
+    lib.dj_set_thread_compute_mode(-1)
+    for direction in (0, 1, 2):
+        for dd in (d, _lib.ConvDesc(4, 10, 10, 64, 10, 10, 64, 3, 3, 1, 1, 1, 1, 1, 1, 64, 64)):
+            for mode in (0, 1, 2):
+                lib.dj_set_thread_compute_mode(mode)
+                _lib.check(lib.dj_conv2d_tune_set(direction, dd, -1, 1), "tune_set")
+    lib.dj_set_thread_compute_mode(-1)

@@ -305,3 +305,67 @@ def test_colsum_multi(cuda):
     torch.cuda.synchronize()
     for o, ref in zip(outs, refs):
         assert torch.equal(o, ref)
+
+
+def test_two_threads_two_arithmetic_modes_through_the_c_abi(cuda):
+    """two host threads launch convolutions at the same time on their own streams, one in exact fp32
+    and one in fp16-MFMA mode (per-thread override of the C library), while a third keeps rewriting the tuner's override
+    table.  Each thread's results must equal what the same calls give alone: the fp32 thread bit for bit."""
+    import threading
+    from jpeg_detection_resnet_ssd_amd import _lib
+    from jpeg_detection_resnet_ssd_amd import kernels as Kn
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(4)
+    desc = Kn.make_conv_desc(4, 19, 19, 128, 128, (3, 3), (1, 1), "same", (1, 1))
+    x = torch.randn(4, 19, 19, 128, generator=g).to(cuda)
+    w = (torch.randn(3, 3, 128, 128, generator=g) * 0.05).to(cuda)
+    bias = torch.randn(128, generator=g).to(cuda)
+
+    def run(mode, n, stream, out):
+        lib.dj_set_thread_compute_mode(mode)
+        with torch.cuda.stream(stream):
+            for i in range(n):
+                y = torch.empty(4, 19, 19, 128, device=cuda)
+                Kn.conv2d_fwd(desc, x, w, bias, y)
+                out.append(y)
+        stream.synchronize()
+        lib.dj_set_thread_compute_mode(-1)
+
+    alone32, alone16 = [], []
+    run(0, 1, torch.cuda.Stream(), alone32)
+    run(1, 1, torch.cuda.Stream(), alone16)
+    assert float((alone32[0] - alone16[0]).abs().max()) > 1e-5      # the two modes really differ
+    stop = threading.Event()
+
+    def retune():
+        other = Kn.make_conv_desc(4, 19, 19, 128, 128, (1, 1), (1, 1), "valid", (1, 1))
+        i = 0
+        while not stop.is_set():
+            lib.dj_conv2d_tune_set(0, other, i % lib.dj_conv2d_tune_configs(), 1)
+            i += 1
+        lib.dj_conv2d_tune_set(0, other, -1, 1)
+
+    out32, out16, errs = [], [], []
+
+    def guarded(*a):
+        try:
+            run(*a)
+        except Exception as e:     # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=guarded, args=(0, 40, torch.cuda.Stream(), out32)),
+          threading.Thread(target=guarded, args=(1, 40, torch.cuda.Stream(), out16)), threading.Thread(target=retune)]
+    for t in ts:
+        t.start()
+    ts[0].join()
+    ts[1].join()
+    stop.set()
+    ts[2].join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    assert len(out32) == 40 and len(out16) == 40
+    for y in out32:
+        assert torch.equal(y, alone32[0])
+    for y in out16:
+        assert torch.equal(y, alone16[0])
+    assert lib.dj_get_compute_mode() == 0
