@@ -323,12 +323,14 @@ def test_two_threads_two_arithmetic_modes_through_the_c_abi(cuda):
 
     def run(mode, n, stream, out):
         lib.dj_set_thread_compute_mode(mode)
+        lib.dj_conv2d_tune_set(0, desc, 2, 1)      # 64x64 tiles, no split-K: no atomics, so bit-reproducible
         with torch.cuda.stream(stream):
             for i in range(n):
                 y = torch.empty(4, 19, 19, 128, device=cuda)
                 Kn.conv2d_fwd(desc, x, w, bias, y)
                 out.append(y)
         stream.synchronize()
+        lib.dj_conv2d_tune_set(0, desc, -1, 1)
         lib.dj_set_thread_compute_mode(-1)
 
     alone32, alone16 = [], []
