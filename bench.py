@@ -120,7 +120,7 @@ def main(json_out=None):
                     help="conv arithmetic: float32 = exact fp32 MFMA (the headline); float16 / bfloat16 = BASELINE config 5's "
                          "reduced-precision MFMA with fp32 master tensors and accumulation (reported with its own dtype)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=8, help="batch of the CPU-oracle sample (BASELINE.md: 8)")
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of CPU work for the cpu_baseline sample")
     args = ap.parse_args()
 
@@ -183,14 +183,23 @@ def main(json_out=None):
         "vs_baseline": None, "dtype": {"float32": "f32", "float16": "f16/bf16-mfma+f32-acc", "bfloat16": "bf16-mfma+f32-acc"}[args.floatx],
         "data": "synthetic",
         "config": {"workload": "SSD300 ResNet50-DCT '%s' archi, %d images/GPU, 300x300 JPEG-DCT inputs "
-                               "(Y 38x38x64 + chroma 19x19), fwd+loss+bwd+SGD(+RCCL all-reduce)" % (args.archi, args.batch),
+                               "(Y 38x38x64 + chroma 19x19), fwd+loss+bwd+SGD(+RCCL all-reduce); batch and encoded targets "
+                               "resident in HBM: host->device upload, target encoding and the per-step loss read-back of "
+                               "fit_generator are outside the timed region (DESIGN.md section 6 has those rates)"
+                               % (args.archi, args.batch),
                    "archi": args.archi, "global_batch": world * args.batch, "parallelism": "dp%d" % world,
-                   "train_gflop_per_image": gflop, "last_loss": loss},
+                   "train_gflop_per_image": gflop, "last_loss": loss,
+                   "multi_gpu": ("data parallel over RCCL, %d ranks" % world) if world > 1 else
+                                "1 GPU; the RCCL exchange has only ever run on a 1-rank communicator (no multi-GPU box "
+                                "was available to the builder): no scaling curve has been measured"},
     }
     roof = {"bound": "mfma", "achieved": per_gpu_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": per_gpu_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
             "note": "whole-step algorithmic conv FLOPs (SURVEY 8(d) table) / step time, per GPU"}
-    traffic_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_igemm_traffic.json")
+    prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    traffic_file = os.path.join(prof, "r02_igemm_traffic.json")
+    if not os.path.exists(traffic_file):
+        traffic_file = os.path.join(prof, "r01_igemm_traffic.json")
     if os.path.exists(traffic_file) and args.archi == "deconv" and args.batch == 32:
         # offline rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_f_hbm_traffic_pmc.md), bytes per launch
         with open(traffic_file) as f:

@@ -4,6 +4,8 @@
 #include "../../include/dj_hip.h"
 #include "dj_igemm.h"
 #include "dj_igemm_fast.h"
+#include "dj_igemm_h16.h"
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------------
 // tile configurations
@@ -125,6 +127,17 @@ template <int BM, int BN, int AM, int BMD, int PREC>
 static int launch_lowp(const DjIgemmParams& p, int splits, hipStream_t s, int fast) {
   using Cfg = DjIgemmCfg<BM, BN, 2, 2, AM, BMD>;
   static bool done[2] = {false, false};
+  // 16-bit tiles in LDS + 16-deep MFMA (dj_igemm_h16.h) for everything but the residual-add prologue, which stays on the
+  // fp32-tile kernel with the fragments rounded at read time (DJ_LOWP_LDS32=1 forces that older path everywhere)
+  static const bool lds32 = getenv("DJ_LOWP_LDS32") != nullptr;
+  if ((fast == 1 || fast == 2) && !lds32) {
+    using H = DjH16Cfg<BM, BN, AM, BMD>;
+    static bool hdone[2] = {false, false};
+    if (fast == 1)
+      return launch_kernel(dj_igemm_h16_kernel<BM, BN, AM, BMD, 0, PREC>, H::SMEM_BYTES, BM, BN, p, splits, s, &hdone[0]);
+    if constexpr (AM != 1)   // the input-gradient GEMM has no prologue
+      return launch_kernel(dj_igemm_h16_kernel<BM, BN, AM, BMD, 1, PREC>, H::SMEM_BYTES, BM, BN, p, splits, s, &hdone[1]);
+  }
   if (fast == 1)
     return launch_kernel(dj_igemm_fast_kernel<BM, BN, 2, 2, AM, BMD, 0, 2, PREC>, Cfg::SMEM_BYTES, BM, BN, p, splits, s,
                          &done[0]);

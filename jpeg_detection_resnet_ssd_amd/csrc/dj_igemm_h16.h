@@ -1,0 +1,308 @@
+// Reduced-precision implicit-GEMM convolution (BASELINE config 5, "fp16 MFMA"; K.set_floatx('float16' / 'bfloat16')):
+// the same three GEMMs as dj_igemm_fast.h (forward, input gradient, weight gradient of keras.layers.Conv2D, reference
+// call sites localisation_part/models/keras_ssd300_dct_j2d_resnet.py:77-96,128-160,483-545,562-675), with the operands
+// rounded to fp16 (forward) or bf16 (gradients) ONCE, when a thread stores its piece of the tile to LDS, and fed to
+// v_mfma_f32_32x32x16_{f16,bf16} -- the 16-deep CDNA4 instruction, fp32 accumulation.  HBM tensors stay fp32.
+//
+// What changed against the PREC != 0 path of dj_igemm_fast.h (fp32 tiles in LDS, every wave converting the fragments it
+// reads, 8-deep MFMA): half the LDS bytes, each element converted once instead of once per reading wave, and half the
+// MFMA instructions per K-step.
+//
+// LDS images (16-bit elements), one K-step = 32 k:
+//   * k-contiguous operand (A of forward / input gradient, B of the input gradient): [rows][32 k], pitch 40 elements
+//     (80 B: 16-byte aligned rows, conflict-free for the 16-lane groups of ds_read_b128).  Lane (row r, half h) reads
+//     k = 16 s + 8 h .. + 7 of MFMA step s with one ds_read_b128: exactly its operand of v_mfma_*_32x32x16.
+//   * the operand that is contiguous along the OTHER GEMM dimension (HWIO weights in the forward pass; both operands of the
+//     weight gradient, whose reduction runs over pixels): stored as it arrives, [32 k][cols], pitch cols + 32 elements,
+//     and read with ds_read_b64_tr_b16, gfx950's transposing LDS read: a 16-lane group hands in 4 row (k) addresses x
+//     16 columns and every lane receives the 4 k values of ITS column -- two of them are a lane's 8-deep operand.  The
+//     pitch puts the 4 rows x 2 column groups of a 32-lane half on 64 different banks.
+// The global-load side (buffer loads with out-of-range offsets for halo / tails, wave-uniform tap state, the
+// BatchNormalization(+ReLU) prologue in fp32 before the rounding, XCD-aware tile order, split-K) and the epilogue are
+// those of the fp32 kernel.
+#pragma once
+#include "dj_igemm.h"
+#include "dj_igemm_fast.h"
+
+typedef short dj_tr4 __attribute__((__vector_size__(4 * sizeof(short))));   // what the transposing read returns
+typedef short dj_s16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 dj_half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 dj_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short __attribute__((address_space(3))) dj_lds_short;
+
+template <int BM, int BN, int AM, int BMD>
+struct DjH16Cfg {
+  static constexpr int TM = BM / 64, TN = BN / 64;   // 4 waves as 2 x 2
+  static constexpr int NA = BM / 32, NB = BN / 32;
+  static constexpr bool A_KC = (AM != 2), B_KC = (BMD == 1);
+  static constexpr int PA = A_KC ? 40 : BM + 32, PB = B_KC ? 40 : BN + 32;   // pitches, in 16-bit elements
+  static constexpr int A_H = (A_KC ? BM : 32) * PA, B_H = (B_KC ? BN : 32) * PB;
+  static constexpr int STAGE_H = A_H + B_H;
+  static constexpr int SMEM_BYTES = 2 * STAGE_H * 2;
+};
+
+template <int PREC>
+__device__ __forceinline__ dj_short4 dj_round4(f32x4 v) {
+  if (PREC == 1) return __builtin_bit_cast(dj_short4, dj_to_half4(v));
+  return dj_to_bf16x4(v);
+}
+
+// PRO: 0 plain A, 1 A*scale[c]+shift[c] (+ReLU) on in-bounds elements.  PREC: 1 fp16, 2 bf16.
+template <int BM, int BN, int AM, int BMD, int PRO, int PREC>
+__global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p) {
+  using Cfg = DjH16Cfg<BM, BN, AM, BMD>;
+  constexpr int TM = Cfg::TM, TN = Cfg::TN, NA = Cfg::NA, NB = Cfg::NB;
+  constexpr int PA = Cfg::PA, PB = Cfg::PB;
+  constexpr int WN = 2;
+  extern __shared__ __attribute__((aligned(16))) float smem_base[];
+  short* const smem = reinterpret_cast<short*>(smem_base);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int tiles_n = (p.N + BN - 1) / BN;
+  int tile_id;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, slot = b >> 3;
+    tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int tile_m = tile_id / tiles_n;
+  const int tile_n = tile_id - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kbeg = blockIdx.y * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
+  const int nk = (kend - kbeg + DJ_BK - 1) / DJ_BK;
+
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)p.pro_scale, 0, PRO ? p.srcC * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void*)p.pro_shift, 0, PRO ? p.srcC * 4 : 0, 0x00020000);
+  const float relu_floor = p.pro_relu ? 0.f : -INFINITY;
+
+  // ---------------- per-thread staging state (as in dj_igemm_fast.h) ----------------
+  const int ac = tid & 7, ar0 = tid >> 3;
+  constexpr int BKSTEP = 1024 / BN;
+  const int bcn = tid % (BN / 4), bkr0 = tid / (BN / 4);
+  const int bc = tid & 7, br0 = tid >> 3;
+
+  int a_off[NA], a_rh[NA], a_rw[NA];
+  int a2_c[NA], a2_dh[NA], a2_dw[NA];
+  bool a2_ok[NA];
+  f32x4 a2_sc[NA], a2_sh[NA];
+  if (AM != 2) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      int m = m0 + ar0 + 32 * j;
+      if (m < p.M) {
+        int img = m / (p.rowH * p.rowW);
+        int rem = m - img * (p.rowH * p.rowW);
+        int h = rem / p.rowW;
+        int w = rem - h * p.rowW;
+        int rh = (AM == 0) ? h * p.sH - p.pT : h + p.pT;
+        int rw = (AM == 0) ? w * p.sW - p.pL : w + p.pL;
+        a_rh[j] = rh;
+        a_rw[j] = rw;
+        a_off[j] = ((img * p.srcH * p.srcW + rh * p.srcW + rw) * p.ldsrc + 4 * ac) * 4;
+      } else {
+        a_rh[j] = -(1 << 28);
+        a_rw[j] = -(1 << 28);
+        a_off[j] = 0;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      int mm = m0 + 4 * (ac + 8 * i);
+      a2_ok[i] = mm < p.M;
+      int tap = mm / p.srcC;
+      a2_c[i] = mm - tap * p.srcC;
+      int kh = tap / p.KW;
+      int kw = tap - kh * p.KW;
+      a2_dh[i] = kh * p.dH - p.pT;
+      a2_dw[i] = kw * p.dW - p.pL;
+      if (PRO) {
+        a2_sc[i] = dj_buf_ld4(rS, a2_ok[i] ? (unsigned)a2_c[i] * 4u : DJ_OOB);
+        a2_sh[i] = dj_buf_ld4(rT, a2_ok[i] ? (unsigned)a2_c[i] * 4u : DJ_OOB);
+      }
+    }
+  }
+  int b_off[NB];
+  bool b_ok[NB];
+  if (BMD == 0) {
+    int n = n0 + 4 * bcn;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      b_ok[j] = n < p.N;
+      b_off[j] = ((bkr0 + BKSTEP * j) * p.ldb + n) * 4;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      int n = n0 + br0 + 32 * j;
+      b_ok[j] = n < p.N;
+      b_off[j] = (n * p.ldb + 4 * bc) * 4;
+    }
+  }
+
+  int t_c0 = 0, t_kh = 0, t_kw = 0, t_tap = 0;
+  if (AM != 2 || BMD == 1) {
+    t_tap = kbeg / p.srcC;
+    t_c0 = kbeg - t_tap * p.srcC;
+    t_kh = t_tap / p.KW;
+    t_kw = t_tap - t_kh * p.KW;
+  }
+
+  f32x4 ra[NA], rb[NB];
+  unsigned a_valid = 0;
+  f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+
+  auto issue_loads = [&](int kcur, bool live) {
+    if (AM != 2) {
+      const int dh = t_kh * p.dH, dw = t_kw * p.dW;
+      const int delta = (AM == 0) ? ((dh * p.srcW + dw) * p.ldsrc + t_c0) * 4 : (-(dh * p.srcW + dw) * p.ldsrc + t_c0) * 4;
+      if (PRO) {
+        psc = dj_buf_ld4(rS, (unsigned)(t_c0 + 4 * ac) * 4u);
+        psh = dj_buf_ld4(rT, (unsigned)(t_c0 + 4 * ac) * 4u);
+      }
+      a_valid = 0;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        int h = (AM == 0) ? a_rh[j] + dh : a_rh[j] - dh;
+        int w = (AM == 0) ? a_rw[j] + dw : a_rw[j] - dw;
+        bool ok = live && (unsigned)h < (unsigned)p.srcH && (unsigned)w < (unsigned)p.srcW;
+        ra[j] = dj_buf_ld4(rA, ok ? (unsigned)(a_off[j] + delta) : DJ_OOB);
+        a_valid |= ok ? (1u << j) : 0u;
+      }
+    } else {
+      a_valid = 0;
+      const int kp = kcur + ar0;
+      const int hw = p.rowH * p.rowW;
+      int img = (int)((float)kp * p.inv_rowHW);
+      int rem = kp - img * hw;
+      int adj = (rem < 0) ? -1 : ((rem >= hw) ? 1 : 0);
+      img += adj;
+      rem -= adj * hw;
+      int oh = (int)((float)rem * p.inv_rowW);
+      int ow = rem - oh * p.rowW;
+      int adj2 = (ow < 0) ? -1 : ((ow >= p.rowW) ? 1 : 0);
+      oh += adj2;
+      ow -= adj2 * p.rowW;
+      const bool rowok = live && kp < kend;
+      const int h0 = oh * p.sH, w0 = ow * p.sW, pb = img * p.srcH * p.srcW;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        int h = h0 + a2_dh[i], w = w0 + a2_dw[i];
+        bool ok = rowok && a2_ok[i] && (unsigned)h < (unsigned)p.srcH && (unsigned)w < (unsigned)p.srcW;
+        unsigned off = (unsigned)((pb + h * p.srcW + w) * p.ldsrc + a2_c[i]) * 4u;
+        ra[i] = dj_buf_ld4(rA, ok ? off : DJ_OOB);
+        a_valid |= ok ? (1u << i) : 0u;
+      }
+    }
+    if (BMD == 0) {
+      const int base = kcur * p.ldb * 4;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        bool ok = live && b_ok[j] && (AM != 2 || kcur + bkr0 + BKSTEP * j < kend);
+        rb[j] = dj_buf_ld4(rB, ok ? (unsigned)(b_off[j] + base) : DJ_OOB);
+      }
+    } else {
+      const unsigned base = (unsigned)(t_tap * p.bTapStride + t_c0) * 4u;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) rb[j] = dj_buf_ld4(rB, (live && b_ok[j]) ? (unsigned)b_off[j] + base : DJ_OOB);
+    }
+    if (AM != 2 || BMD == 1) {
+      t_c0 += DJ_BK;
+      const int wrap = (t_c0 >= p.srcC) ? 1 : 0;
+      t_c0 = wrap ? 0 : t_c0;
+      t_tap += wrap;
+      t_kw += wrap;
+      const int wrap2 = (t_kw >= p.KW) ? 1 : 0;
+      t_kw = wrap2 ? 0 : t_kw;
+      t_kh += wrap2;
+    }
+  };
+
+  // prologue in fp32, then ONE rounding per element, 8-byte LDS stores
+  auto store_tiles = [&](short* sA, short* sB) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      f32x4 v = ra[j];
+      if (PRO) {
+        f32x4 sc = (AM == 2) ? a2_sc[j] : psc, sh = (AM == 2) ? a2_sh[j] : psh;
+        v = v * sc + sh;
+        bool ok = (a_valid >> j) & 1u;
+        v.x = ok ? fmaxf(v.x, relu_floor) : 0.f;
+        v.y = ok ? fmaxf(v.y, relu_floor) : 0.f;
+        v.z = ok ? fmaxf(v.z, relu_floor) : 0.f;
+        v.w = ok ? fmaxf(v.w, relu_floor) : 0.f;
+      }
+      short* dst = (AM != 2) ? sA + (ar0 + 32 * j) * PA + 4 * ac : sA + ar0 * PA + 4 * (ac + 8 * j);
+      *reinterpret_cast<dj_short4*>(dst) = dj_round4<PREC>(v);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      short* dst = (BMD == 0) ? sB + (bkr0 + BKSTEP * j) * PB + 4 * bcn : sB + (br0 + 32 * j) * PB + 4 * bc;
+      *reinterpret_cast<dj_short4*>(dst) = dj_round4<PREC>(rb[j]);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // lane constants of the fragment reads
+  //  k-contiguous image: element offset of (row l31, k = 8 h) inside a 32-row tile
+  //  transposed image: lane 4q + p of a 16-lane group addresses row (k) q, columns 4p .. 4p+3; the group's columns are
+  //  16 * ((lane >> 4) & 1) .. + 15 of the 32-column tile; the lane half picks the k half (8 h)
+  const int kc_a = l31 * PA + 8 * lh, kc_b = l31 * PB + 8 * lh;
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+  const int tr_a = (8 * lh + tq) * PA + 16 * tg + 4 * tp, tr_b = (8 * lh + tq) * PB + 16 * tg + 4 * tp;
+
+  auto frag = [&](const short* img, bool kc, int kc_off, int tr_off, int pitch, int tile, int s) -> dj_s16x8 {
+    if (kc) return *reinterpret_cast<const dj_s16x8*>(img + tile * 32 * pitch + kc_off + 16 * s);
+    const short* q = img + tr_off + tile * 32 + 16 * s * pitch;
+    dj_tr4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dj_tr4 __attribute__((address_space(3)))*)(dj_lds_short*)q);
+    dj_tr4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dj_tr4 __attribute__((address_space(3)))*)(dj_lds_short*)(q + 4 * pitch));
+    return dj_s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  };
+  auto compute = [&](const short* sA, const short* sB, int s) {
+    dj_s16x8 fa[TM], fb[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = frag(sA, Cfg::A_KC, kc_a, tr_a, PA, wm * TM + i, s);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[j] = frag(sB, Cfg::B_KC, kc_b, tr_b, PB, wn * TN + j, s);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (PREC == 1)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(dj_half8, fa[i]),
+                                                             __builtin_bit_cast(dj_half8, fb[j]), acc[i][j], 0, 0, 0);
+        else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dj_bf16x8, fa[i]),
+                                                              __builtin_bit_cast(dj_bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+      }
+  };
+
+  // two LDS stages: tile kt+1 is loaded and stored while tile kt is multiplied
+  issue_loads(kbeg, nk > 0);
+  store_tiles(smem, smem + Cfg::A_H);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    short* cur = smem + (kt & 1) * Cfg::STAGE_H;
+    short* nxt = smem + ((kt + 1) & 1) * Cfg::STAGE_H;
+    issue_loads(kbeg + (kt + 1) * DJ_BK, kt + 1 < nk);
+    compute(cur, cur + Cfg::A_H, 0);
+    store_tiles(nxt, nxt + Cfg::A_H);
+    compute(cur, cur + Cfg::A_H, 1);
+    __syncthreads();
+  }
+  dj_igemm_epilogue<BM, BN, 2, 2>(p, acc, smem_base, tile_m, m0, n0);
+}
