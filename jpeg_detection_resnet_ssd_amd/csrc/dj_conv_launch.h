@@ -127,9 +127,16 @@ template <int BM, int BN, int AM, int BMD, int PREC>
 static int launch_lowp(const DjIgemmParams& p, int splits, hipStream_t s, int fast) {
   using Cfg = DjIgemmCfg<BM, BN, 2, 2, AM, BMD>;
   static bool done[2] = {false, false};
-  // 16-bit tiles in LDS + 16-deep MFMA (dj_igemm_h16.h) for everything but the residual-add prologue, which stays on the
-  // fp32-tile kernel with the fragments rounded at read time (DJ_LOWP_LDS32=1 forces that older path everywhere)
+  // 16-bit tiles in LDS + 16-deep MFMA (dj_igemm_h16.h); DJ_LOWP_LDS32=1 keeps the older path (fp32 tiles, fragments
+  // rounded at read time, 8-deep MFMA) for A/B runs
   static const bool lds32 = getenv("DJ_LOWP_LDS32") != nullptr;
+  if (fast == 3 && !lds32) {
+    if constexpr (AM == 0 && BMD == 0) {
+      using H = DjH16Cfg<BM, BN, AM, BMD>;
+      static bool hdone3 = false;
+      return launch_kernel(dj_igemm_h16_kernel<BM, BN, AM, BMD, 3, PREC>, H::SMEM_BYTES, BM, BN, p, splits, s, &hdone3);
+    }
+  }
   if ((fast == 1 || fast == 2) && !lds32) {
     using H = DjH16Cfg<BM, BN, AM, BMD>;
     static bool hdone[2] = {false, false};

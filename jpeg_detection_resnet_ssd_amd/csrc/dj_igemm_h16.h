@@ -47,7 +47,9 @@ __device__ __forceinline__ dj_short4 dj_round4(f32x4 v) {
   return dj_to_bf16x4(v);
 }
 
-// PRO: 0 plain A, 1 A*scale[c]+shift[c] (+ReLU) on in-bounds elements.  PREC: 1 fp16, 2 bf16.
+// PRO: 0 plain A, 1 A*scale[c]+shift[c] (+ReLU) on in-bounds elements, 3 the residual-add prologue of the forward 1x1
+// convolutions, relu(A*scale+shift + A2*scale2+shift2), whose column-tile-0 workgroups also store that sum (fp32) to
+// p.sum_out (see dj_igemm_fast.h).  PREC: 1 fp16, 2 bf16.
 template <int BM, int BN, int AM, int BMD, int PRO, int PREC>
 __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p) {
   using Cfg = DjH16Cfg<BM, BN, AM, BMD>;
@@ -80,7 +82,10 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)p.pro_scale, 0, PRO ? p.srcC * 4 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void*)p.pro_shift, 0, PRO ? p.srcC * 4 : 0, 0x00020000);
-  const float relu_floor = p.pro_relu ? 0.f : -INFINITY;
+  const float relu_floor = (p.pro_relu || PRO == 3) ? 0.f : -INFINITY;
+  const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A2, 0, PRO == 3 ? p.a2_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)p.sum_out, 0, (PRO == 3 && p.sum_out) ? p.sum_bytes : 0, 0x00020000);
+  const bool store_sum = (PRO == 3) && p.sum_out != nullptr && tile_n == 0;
 
   // ---------------- per-thread staging state (as in dj_igemm_fast.h) ----------------
   const int ac = tid & 7, ar0 = tid >> 3;
@@ -89,6 +94,7 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
   const int bc = tid & 7, br0 = tid >> 3;
 
   int a_off[NA], a_rh[NA], a_rw[NA];
+  int r2_off[PRO == 3 ? NA : 1], y_off[PRO == 3 ? NA : 1];   // PRO 3: the same pixel in A2 / sum_out
   int a2_c[NA], a2_dh[NA], a2_dw[NA];
   bool a2_ok[NA];
   f32x4 a2_sc[NA], a2_sh[NA];
@@ -106,10 +112,18 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
         a_rh[j] = rh;
         a_rw[j] = rw;
         a_off[j] = ((img * p.srcH * p.srcW + rh * p.srcW + rw) * p.ldsrc + 4 * ac) * 4;
+        if (PRO == 3) {
+          r2_off[j] = (m * p.ldsrc2 + 4 * ac) * 4;
+          y_off[j] = (m * p.ld_sum + 4 * ac) * 4;
+        }
       } else {
         a_rh[j] = -(1 << 28);
         a_rw[j] = -(1 << 28);
         a_off[j] = 0;
+        if (PRO == 3) {
+          r2_off[j] = 0;
+          y_off[j] = 0;
+        }
       }
     }
   } else {
@@ -158,14 +172,27 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
   f32x4 ra[NA], rb[NB];
   unsigned a_valid = 0;
   f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+  f32x4 ra2[PRO == 3 ? NA : 1], psc2 = {1.f, 1.f, 1.f, 1.f}, psh2 = {0.f, 0.f, 0.f, 0.f};
+  int pro_c0 = 0;
 
   auto issue_loads = [&](int kcur, bool live) {
     if (AM != 2) {
       const int dh = t_kh * p.dH, dw = t_kw * p.dW;
       const int delta = (AM == 0) ? ((dh * p.srcW + dw) * p.ldsrc + t_c0) * 4 : (-(dh * p.srcW + dw) * p.ldsrc + t_c0) * 4;
-      if (PRO) {
+      if (PRO == 1) {
         psc = dj_buf_ld4(rS, (unsigned)(t_c0 + 4 * ac) * 4u);
         psh = dj_buf_ld4(rT, (unsigned)(t_c0 + 4 * ac) * 4u);
+      }
+      if (PRO == 3) {   // plain loads from uniform bases: fewer descriptors live in the loop (see dj_igemm_fast.h)
+        pro_c0 = t_c0;
+        psc = dj_ld4(p.pro_scale + (t_c0 + 4 * ac));
+        psh = dj_ld4(p.pro_shift + (t_c0 + 4 * ac));
+        psc2 = f32x4{1.f, 1.f, 1.f, 1.f};
+        psh2 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.pro_scale2) {
+          psc2 = dj_ld4(p.pro_scale2 + (t_c0 + 4 * ac));
+          psh2 = dj_ld4(p.pro_shift2 + (t_c0 + 4 * ac));
+        }
       }
       a_valid = 0;
 #pragma unroll
@@ -174,6 +201,7 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
         int w = (AM == 0) ? a_rw[j] + dw : a_rw[j] - dw;
         bool ok = live && (unsigned)h < (unsigned)p.srcH && (unsigned)w < (unsigned)p.srcW;
         ra[j] = dj_buf_ld4(rA, ok ? (unsigned)(a_off[j] + delta) : DJ_OOB);
+        if (PRO == 3) ra2[j] = dj_buf_ld4(rA2, ok ? (unsigned)(r2_off[j] + t_c0 * 4) : DJ_OOB);
         a_valid |= ok ? (1u << j) : 0u;
       }
     } else {
@@ -233,11 +261,15 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
       if (PRO) {
         f32x4 sc = (AM == 2) ? a2_sc[j] : psc, sh = (AM == 2) ? a2_sh[j] : psh;
         v = v * sc + sh;
+        if (PRO == 3) v += ra2[j] * psc2 + psh2;
         bool ok = (a_valid >> j) & 1u;
         v.x = ok ? fmaxf(v.x, relu_floor) : 0.f;
         v.y = ok ? fmaxf(v.y, relu_floor) : 0.f;
         v.z = ok ? fmaxf(v.z, relu_floor) : 0.f;
         v.w = ok ? fmaxf(v.w, relu_floor) : 0.f;
+        if (PRO == 3 && store_sum)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rY,
+                                                 ok ? (int)(y_off[j] + pro_c0 * 4) : (int)DJ_OOB, 0, 0);
       }
       short* dst = (AM != 2) ? sA + (ar0 + 32 * j) * PA + 4 * ac : sA + ar0 * PA + 4 * (ac + 8 * j);
       *reinterpret_cast<dj_short4*>(dst) = dj_round4<PREC>(v);
