@@ -58,6 +58,18 @@ static int launch_one(const DjIgemmParams& p, int splits, hipStream_t s, int fas
   using Cfg = DjIgemmCfg<BM, BN, WM, WN, AM, BMD>;
   static bool done[3] = {false, false, false};
   const int smem_fast = Cfg::SMEM_BYTES / 2 * ((NSTAGE == 2 || NSTAGE == 4) ? 2 : 1);
+  if constexpr (AM != 2) {
+    // 1x1 kernels without padding: the variant that does no per-K-step bounds arithmetic (NP, see dj_igemm_fast.h)
+    static const bool np_off = getenv("DJ_NO_NP") != nullptr;
+    if ((fast == 1 || fast == 2) && p.KH == 1 && p.KW == 1 && p.pT == 0 && p.pL == 0 && !np_off) {
+      static bool npdone[2] = {false, false};
+      if (fast == 1)
+        return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 0, NSTAGE, 0, 1, 1>, smem_fast, BM, BN, p, splits,
+                             s, &npdone[0]);
+      return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 1, NSTAGE, 0, 1, 1>, smem_fast, BM, BN, p, splits, s,
+                           &npdone[1]);
+    }
+  }
   if (fast == 1)
     return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 0, NSTAGE>, smem_fast, BM, BN, p, splits, s,
                          &done[1]);

@@ -50,8 +50,14 @@ __device__ __forceinline__ dj_short4 dj_to_bf16x4(f32x4 v) {
 // KS: 1, or 2 = two 256-thread groups per workgroup, each with its own LDS ring, take alternate K-steps of the SAME
 //       output tile and add their accumulators through LDS before the epilogue: twice the waves per SIMD for launches
 //       that have too few tiles to fill the CUs (19x19 and 10x10 maps at batch 32), no atomics, BN statistics intact.
-template <int BM, int BN, int WM, int WN, int AM, int BMD, int PRO, int NSTAGE = 2, int PREC = 0, int KS = 1>
+// NP: 1 = the gathered operand can never leave its tensor (1x1 kernel, no padding; A-modes 0/1, PRO 0/1, KS 1): the row
+//       validity is a per-row constant, so the K-step spends no vector instruction on coordinates, bounds tests and
+//       offset selects -- on gfx950 the fp32 MFMA and the vector ALU do not overlap (tools/micro/mfma_valu.hip: every
+//       VALU instruction adds its ~5 cycles to the 64 of a v_mfma_f32_32x32x2_f32), and two thirds of the convolutions
+//       of a bottleneck block are 1x1.  Rows past M carry an offset that stays out of range whatever is added to it.
+template <int BM, int BN, int WM, int WN, int AM, int BMD, int PRO, int NSTAGE = 2, int PREC = 0, int KS = 1, int NP = 0>
 __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmParams p) {
+  static_assert(NP == 0 || (AM != 2 && PRO != 3 && KS == 1), "NP: 1x1 gathers of the k-contiguous A operand only");
   using Cfg = DjIgemmCfg<BM, BN, WM, WN, AM, BMD>;
   constexpr int TM = Cfg::TM, TN = Cfg::TN, NA = Cfg::NA, NB = Cfg::NB;
   constexpr int LDA_S = Cfg::LDA_S, LDB_S = Cfg::LDB_S;
@@ -116,10 +122,12 @@ __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmPa
   int a2_c[NA], a2_dh[NA], a2_dw[NA];
   bool a2_ok[NA];
   f32x4 a2_sc[NA], a2_sh[NA];
+  unsigned row_valid = 0;                 // NP: bit j = row j of this thread exists
   if (AM != 2) {
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       int m = m0 + ar0 + 32 * j;
+      row_valid |= (m < p.M) ? (1u << j) : 0u;
       if (m < p.M) {
         int img = m / (p.rowH * p.rowW);
         int rem = m - img * (p.rowH * p.rowW);
@@ -137,7 +145,7 @@ __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmPa
       } else {
         a_rh[j] = -(1 << 28);
         a_rw[j] = -(1 << 28);
-        a_off[j] = 0;
+        a_off[j] = NP ? (int)0x80000000 : 0;
         if (PRO == 3) {
           a2_off[j] = 0;
           y_off[j] = 0;
@@ -229,9 +237,14 @@ __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmPa
           R.psh2 = dj_ld4(p.pro_shift2 + (t_c0 + 4 * ac));
         }
       }
-      a_valid = 0;
+      a_valid = NP ? row_valid : 0u;
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
+        if (NP) {
+          // (a prefetch past the last K-step reads other, finite, data of the same tensor or nothing: never consumed)
+          ra[j] = dj_buf_ld4(rA, (unsigned)(a_off[j] + delta));
+          continue;
+        }
         int h = (AM == 0) ? a_rh[j] + dh : a_rh[j] - dh;
         int w = (AM == 0) ? a_rw[j] + dw : a_rw[j] - dw;
         bool ok = live && (unsigned)h < (unsigned)p.srcH && (unsigned)w < (unsigned)p.srcW;
