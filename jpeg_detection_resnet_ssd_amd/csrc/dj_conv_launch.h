@@ -58,10 +58,12 @@ static int launch_one(const DjIgemmParams& p, int splits, hipStream_t s, int fas
   using Cfg = DjIgemmCfg<BM, BN, WM, WN, AM, BMD>;
   static bool done[3] = {false, false, false};
   const int smem_fast = Cfg::SMEM_BYTES / 2 * ((NSTAGE == 2 || NSTAGE == 4) ? 2 : 1);
-  if constexpr (AM != 2) {
-    // 1x1 kernels without padding: the variant that does no per-K-step bounds arithmetic (NP, see dj_igemm_fast.h)
+  {
+    // 1x1 kernels without padding: the variant that does no per-K-step bounds arithmetic (NP, see dj_igemm_fast.h); for
+    // the weight gradient also stride 1 (input pixel == output pixel)
     static const bool np_off = getenv("DJ_NO_NP") != nullptr;
-    if ((fast == 1 || fast == 2) && p.KH == 1 && p.KW == 1 && p.pT == 0 && p.pL == 0 && !np_off) {
+    const bool same_grid = (AM != 2) || (p.sH == 1 && p.sW == 1 && p.rowH == p.srcH && p.rowW == p.srcW);
+    if ((fast == 1 || fast == 2) && p.KH == 1 && p.KW == 1 && p.pT == 0 && p.pL == 0 && same_grid && !np_off) {
       static bool npdone[2] = {false, false};
       if (fast == 1)
         return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 0, NSTAGE, 0, 1, 1>, smem_fast, BM, BN, p, splits,

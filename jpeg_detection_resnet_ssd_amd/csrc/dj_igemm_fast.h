@@ -55,9 +55,11 @@ __device__ __forceinline__ dj_short4 dj_to_bf16x4(f32x4 v) {
 //       offset selects -- on gfx950 the fp32 MFMA and the vector ALU do not overlap (tools/micro/mfma_valu.hip: every
 //       VALU instruction adds its ~5 cycles to the 64 of a v_mfma_f32_32x32x2_f32), and two thirds of the convolutions
 //       of a bottleneck block are 1x1.  Rows past M carry an offset that stays out of range whatever is added to it.
+//       Weight gradient (A-mode 2, stride 1): the input pixel IS the output pixel, so a thread's x row advances by a
+//       constant per K-step -- no pixel decomposition, no coordinate tests (pixels past the chunk meet zero dy rows).
 template <int BM, int BN, int WM, int WN, int AM, int BMD, int PRO, int NSTAGE = 2, int PREC = 0, int KS = 1, int NP = 0>
 __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmParams p) {
-  static_assert(NP == 0 || (AM != 2 && PRO != 3 && KS == 1), "NP: 1x1 gathers of the k-contiguous A operand only");
+  static_assert(NP == 0 || (PRO != 3 && KS == 1), "NP: no residual-add prologue, no in-workgroup K split");
   using Cfg = DjIgemmCfg<BM, BN, WM, WN, AM, BMD>;
   constexpr int TM = Cfg::TM, TN = Cfg::TN, NA = Cfg::NA, NB = Cfg::NB;
   constexpr int LDA_S = Cfg::LDA_S, LDB_S = Cfg::LDB_S;
@@ -167,8 +169,13 @@ __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmPa
         a2_sc[i] = dj_buf_ld4(rS, a2_ok[i] ? (unsigned)a2_c[i] * 4u : DJ_OOB);
         a2_sh[i] = dj_buf_ld4(rT, a2_ok[i] ? (unsigned)a2_c[i] * 4u : DJ_OOB);
       }
+      row_valid |= a2_ok[i] ? (1u << i) : 0u;
+      if (NP) a2_c[i] = a2_ok[i] ? a2_c[i] * 4 : (int)0x80000000;    // byte offset of the chunk inside its pixel
     }
   }
+  // NP, A-mode 2: byte offset of this thread's pixel row (pixel kbeg + ar0 of the first K-step), advanced per K-step
+  int np_row = (NP && AM == 2) ? (kbeg + ar0) * p.ldsrc * 4 : 0;
+  const int np_step = DJ_BK * p.ldsrc * 4;
   int b_off[NB];
   bool b_ok[NB];
   if (BMD == 0) {
@@ -252,6 +259,11 @@ __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmPa
         if (PRO == 3) R.ra2[j] = dj_buf_ld4(rA2, ok ? (unsigned)(a2_off[j] + t_c0 * 4) : DJ_OOB);
         a_valid |= ok ? (1u << j) : 0u;
       }
+    } else if (NP) {
+      a_valid = row_valid;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) ra[i] = dj_buf_ld4(rA, (unsigned)(np_row + a2_c[i]));
+      np_row += np_step;
     } else {
       a_valid = 0;
       const int kp = kcur + ar0;
