@@ -22,6 +22,16 @@ import numpy as np
 import torch
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA
+PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s measured with a float4 copy)
+
+
+def conv_bytes(desc):
+    """Algorithmic HBM bytes of one conv launch in any direction: its two fp32 operands read once, its result written once
+    (x, w, y of the geometry; padding columns of a fused predictor-head filter bank are not counted)."""
+    out_c = getattr(desc, "algorithmic_out_c", desc.out_c)
+    return 4.0 * (desc.batch * desc.in_h * desc.in_w * desc.in_c + desc.kernel_h * desc.kernel_w * desc.in_c * out_c
+                  + desc.batch * desc.out_h * desc.out_w * out_c)
 
 
 def conv_flops(desc):
@@ -45,7 +55,7 @@ def measure_conv_kernels(model, plan):
             e0.record()
             r = f(desc, *a, **kw)
             e1.record()
-            records.append((e0, e1, conv_flops(desc)))
+            records.append((e0, e1, conv_flops(desc), conv_bytes(desc)))
             return r
         setattr(Kn, name, timed)
 
@@ -59,9 +69,9 @@ def measure_conv_kernels(model, plan):
         plan.side_enabled = True
         for n, f in originals.items():
             setattr(Kn, n, f)
-    total_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in records)
-    flop = sum(fl for _, _, fl in records)
-    return dict(total_ms=total_ms, flop=flop, launches=len(records))
+    total_ms = sum(r[0].elapsed_time(r[1]) for r in records)
+    flop = sum(r[2] for r in records)
+    return dict(total_ms=total_ms, flop=flop, launches=len(records), bytes=sum(r[3] for r in records))
 
 
 def available_cores():
@@ -197,8 +207,8 @@ def main(json_out=None):
             "frac": per_gpu_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
             "note": "whole-step algorithmic conv FLOPs (SURVEY 8(d) table) / step time, per GPU"}
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    traffic_file = os.path.join(prof, "r02_igemm_traffic.json")
-    if not os.path.exists(traffic_file):
+    traffic_file = os.path.join(prof, "r02_igemm_traffic.json" if args.floatx == "float32" else "r02_igemm_traffic_f16.json")
+    if not os.path.exists(traffic_file) and args.floatx == "float32":
         traffic_file = os.path.join(prof, "r01_igemm_traffic.json")
     if os.path.exists(traffic_file) and args.archi == "deconv" and args.batch == 32:
         # offline rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_f_hbm_traffic_pmc.md), bytes per launch
@@ -210,7 +220,20 @@ def main(json_out=None):
         roof["dominant_kernel"] = {"name": "dj_igemm_kernel (conv fwd/dgrad/wgrad)", "launches_per_step": k["launches"],
                                    "avg_launch_us": 1e3 * k["total_ms"] / k["launches"],
                                    "ms_per_step": k["total_ms"], "achieved": ktf, "frac": ktf / PEAK_FP32_MFMA_TFLOPS,
-                                   "algorithmic_gflop_per_step": k["flop"] / 1e9}
+                                   "algorithmic_gflop_per_step": k["flop"] / 1e9,
+                                   "algorithmic_gbyte_per_step": k["bytes"] / 1e9,
+                                   "algorithmic_gbyte_per_s": k["bytes"] / (k["total_ms"] * 1e-3) / 1e9}
+        if args.floatx != "float32":
+            # reduced-precision MFMA over fp32 tensors: the GEMMs are ~16x cheaper, reading / writing the fp32 operands
+            # is what bounds the family (2.4 TF of arithmetic per GB moved at these shapes against a machine balance of
+            # 2500 TF / 8 TB/s = 312 FLOP/B): the roofline of this mode is HBM
+            gbps = k["bytes"] / (k["total_ms"] * 1e-3) / 1e9
+            roof.update({"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+                         "note": "implicit-GEMM family: algorithmic bytes (each fp32 operand read once, result written once) "
+                                 "/ its kernel time; the arithmetic side is in `mfma`",
+                         "mfma": {"achieved": per_gpu_tflops, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": per_gpu_tflops / PEAK_F16_MFMA_TFLOPS, "kernel_family_tflops": ktf}})
+            roof["dominant_kernel"]["frac"] = gbps / PEAK_HBM_GBPS
     out["roofline"] = roof
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.archi, args.cpu_batch, args.cpu_budget)

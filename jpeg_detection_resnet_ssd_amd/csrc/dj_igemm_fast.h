@@ -328,7 +328,9 @@ __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmPa
         f32x4 sc = (AM == 2) ? a2_sc[j] : psc, sh = (AM == 2) ? a2_sh[j] : psh;
         f32x4 v = ra[j] * sc + sh;
         if (PRO == 3) v += R.ra2[j] * R.psc2 + R.psh2;
-        bool ok = (a_valid >> j) & 1u;
+        // NP weight gradient: nothing to zero -- a chunk past M has zero scale AND shift (out-of-range loads), a pixel
+        // past the chunk meets a zero dy row
+        bool ok = (NP && AM == 2) ? true : (bool)((a_valid >> j) & 1u);
         v.x = ok ? fmaxf(v.x, relu_floor) : 0.f;
         v.y = ok ? fmaxf(v.y, relu_floor) : 0.f;
         v.z = ok ? fmaxf(v.z, relu_floor) : 0.f;
