@@ -57,9 +57,14 @@ __device__ __forceinline__ dj_short4 dj_to_bf16x4(f32x4 v) {
 //       of a bottleneck block are 1x1.  Rows past M carry an offset that stays out of range whatever is added to it.
 //       Weight gradient (A-mode 2, stride 1): the input pixel IS the output pixel, so a thread's x row advances by a
 //       constant per K-step -- no pixel decomposition, no coordinate tests (pixels past the chunk meet zero dy rows).
+//   2 = kernels with taps / padding (A-modes 0/1, PRO 0/1, KS 1): a row's offset under the CURRENT filter tap (or an
+//       out-of-range marker where the tap leaves the image) is kept in a register and recomputed only when the prefetch
+//       moves on to the next tap -- a wave-uniform branch taken once per in_c / 32 K-steps; the other K-steps add the
+//       channel position to it and nothing else.
 template <int BM, int BN, int WM, int WN, int AM, int BMD, int PRO, int NSTAGE = 2, int PREC = 0, int KS = 1, int NP = 0>
 __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmParams p) {
   static_assert(NP == 0 || (PRO != 3 && KS == 1), "NP: no residual-add prologue, no in-workgroup K split");
+  static_assert(NP != 2 || AM != 2, "NP 2 (per-tap offsets) is for the k-contiguous A operand");
   using Cfg = DjIgemmCfg<BM, BN, WM, WN, AM, BMD>;
   constexpr int TM = Cfg::TM, TN = Cfg::TN, NA = Cfg::NA, NB = Cfg::NB;
   constexpr int LDA_S = Cfg::LDA_S, LDB_S = Cfg::LDB_S;
@@ -203,6 +208,26 @@ __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmPa
     t_kw = t_tap - t_kh * p.KW;
   }
 
+  // NP 2: per-row offsets under the tap the NEXT issue_loads will read
+  int a_tap[NP == 2 ? NA : 1];
+  unsigned tap_valid = 0;
+  auto recompute_tap = [&]() {
+    if (NP == 2) {
+      const int dh = t_kh * p.dH, dw = t_kw * p.dW;
+      const int tapdelta = (AM == 0) ? (dh * p.srcW + dw) * p.ldsrc * 4 : -(dh * p.srcW + dw) * p.ldsrc * 4;
+      tap_valid = 0;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        const int h = (AM == 0) ? a_rh[j] + dh : a_rh[j] - dh;
+        const int w = (AM == 0) ? a_rw[j] + dw : a_rw[j] - dw;
+        const bool ok = ((unsigned)h < (unsigned)p.srcH) & ((unsigned)w < (unsigned)p.srcW);
+        a_tap[j] = ok ? a_off[j] + tapdelta : (int)0x80000000;   // stays out of range with any channel offset added
+        tap_valid |= ok ? (1u << j) : 0u;
+      }
+    }
+  };
+  recompute_tap();
+
   // one K-step's operands in flight: registers between the buffer loads and the LDS writes
   struct Regs {
     f32x4 ra[NA], rb[NB];
@@ -244,9 +269,13 @@ __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmPa
           R.psh2 = dj_ld4(p.pro_shift2 + (t_c0 + 4 * ac));
         }
       }
-      a_valid = NP ? row_valid : 0u;
+      a_valid = (NP == 1) ? row_valid : ((NP == 2) ? tap_valid : 0u);
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
+        if (NP == 2) {
+          ra[j] = dj_buf_ld4(rA, (unsigned)(a_tap[j] + t_c0 * 4));
+          continue;
+        }
         if (NP) {
           // (a prefetch past the last K-step reads other, finite, data of the same tensor or nothing: never consumed)
           ra[j] = dj_buf_ld4(rA, (unsigned)(a_off[j] + delta));
@@ -314,6 +343,7 @@ __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmPa
         const int wrap2 = (t_kw >= p.KW) ? 1 : 0;
         t_kw = wrap2 ? 0 : t_kw;
         t_kh += wrap2;
+        if (NP == 2 && wrap) recompute_tap();     // wave-uniform: the next K-step starts a new tap
       }
     }
   };
