@@ -381,7 +381,14 @@ class Conv2D(Layer):
         pro = (x.scale, x.shift, x.relu) if x.is_affine else (None, None, False)
         stats = fused_bn = None
         consumers = model.consumers_of(self.outbound[0])
-        if (plan.training and not relu and len(consumers) == 1 and isinstance(consumers[0], BatchNormalization)):
+        bn_consumer = (plan.training and not relu and len(consumers) == 1 and isinstance(consumers[0], BatchNormalization))
+        # Fewer 64x64 output tiles than CUs (the 5x5 / 10x10 stages at batch 32): such a GEMM only fills the chip when its
+        # reduction is split over workgroups, and a split launch cannot take the BatchNormalization statistics in its
+        # epilogue (every workgroup holds a partial sum).  There the statistics come from one short column pass over the
+        # (small) result instead -- dj_colstats_partial, what BatchNormalization.lower emits without conv statistics.
+        few_tiles = (-(-(b * desc.out_h * desc.out_w) // 64)) * (-(-self.filters // 64)) < 256
+        split_instead = bn_consumer and few_tiles and os.environ.get("DJ_SPLIT_SMALL_BN", "1") != "0"
+        if bn_consumer and not split_instead:
             if os.environ.get("DJ_FUSE_BNFIN", "0") == "1":
                 # opt-in: the conv's last workgroup turns the column sums into the BatchNormalization coefficients itself
                 # (fp64 accumulators + a ticket, both left zero by that workgroup).  Saves the finalize launch but every
@@ -434,7 +441,7 @@ class Conv2D(Layer):
                 rows, c, ld = rows_of(dy)
                 plan.emit_bwd(lambda: call("dj_relu_bwd", dy, ld, y, c, dy, ld, rows, c, 0))
             if self.bias is not None and self.bias.trainable:
-                if stats is not None or fused_bn is not None:
+                if bn_consumer:
                     # the only consumer is a training-mode BatchNormalization: it subtracts the batch mean, so
                     # d loss / d bias = sum(dz) is identically zero (TF's autodiff returns rounding noise);
                     # the gradient buffer is zero-initialised and simply left untouched
