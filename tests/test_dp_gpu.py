@@ -168,4 +168,8 @@ def test_one_rank_rccl_exchange_in_the_step(cuda, monkeypatch):
     print("one-rank RCCL: %d buckets, |dw| max %.3e, plain-vs-plain %.3e, dist-vs-plain %.3e"
           % (res["n_buckets"], step, spread, err))
     assert step > 0 and err <= max(4 * spread, 2e-4 * step)
-    assert res["l_dist"] == pytest.approx(res["l_plain"], rel=1e-5)
+    # the first loss sees identical weights; later ones inherit the arrival-order noise of the split-K atomics (weight
+    # gradients, and the forward of the few-tile BatchNormalization-fed convolutions), which small-batch statistics
+    # amplify: 1e-4 relative between two PLAIN runs is normal, a wrong exchange is orders of magnitude above
+    assert res["l_dist"][0] == pytest.approx(res["l_plain"][0], rel=1e-5)
+    assert res["l_dist"] == pytest.approx(res["l_plain"], rel=2e-3)
