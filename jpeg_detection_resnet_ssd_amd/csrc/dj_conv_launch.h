@@ -71,6 +71,18 @@ static int launch_one(const DjIgemmParams& p, int splits, hipStream_t s, int fas
       return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 1, NSTAGE, 0, 1, 1>, smem_fast, BM, BN, p, splits, s,
                            &npdone[1]);
     }
+    if constexpr (AM == 2) {
+      // weight gradient with taps / padding / stride whose tiles lie under one tap each: incremental pixel walk (NP 3)
+      static const bool walk_off = getenv("DJ_NO_WALK") != nullptr;
+      if ((fast == 1 || fast == 2) && !np_off && !walk_off && p.srcC % BM == 0) {
+        static bool wkdone[2] = {false, false};
+        if (fast == 1)
+          return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 0, NSTAGE, 0, 1, 3>, smem_fast, BM, BN, p, splits,
+                               s, &wkdone[0]);
+        return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 1, NSTAGE, 0, 1, 3>, smem_fast, BM, BN, p, splits, s,
+                             &wkdone[1]);
+      }
+    }
     if constexpr (AM != 2) {
       // kernels with taps / padding: per-tap row offsets cached across the K-steps of a tap (NP 2)
       static const bool ht_off = getenv("DJ_NO_TAPCACHE") != nullptr;

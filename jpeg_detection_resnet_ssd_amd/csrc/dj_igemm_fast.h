@@ -61,10 +61,17 @@ __device__ __forceinline__ dj_short4 dj_to_bf16x4(f32x4 v) {
 //       out-of-range marker where the tap leaves the image) is kept in a register and recomputed only when the prefetch
 //       moves on to the next tap -- a wave-uniform branch taken once per in_c / 32 K-steps; the other K-steps add the
 //       channel position to it and nothing else.
+//   3 = weight gradient with taps / padding / stride (A-mode 2) when in_c is a multiple of BM: the tile's BM rows lie
+//       under ONE filter tap, and a thread's pixel moves by the same number of pixels every K-step.  The pixel is
+//       decomposed once; afterwards (ow, oh) and the byte offset of the tapped input pixel advance by wave-uniform
+//       constants with two carries (row end, image end) -- ~15 vector instructions per K-step where the float-reciprocal
+//       decomposition, the per-chunk tap arithmetic and its three integer multiplies took ~75 (64x64 tile: 134 -> ~75
+//       per 16 MFMAs, and the multiplies are quarter rate).
 template <int BM, int BN, int WM, int WN, int AM, int BMD, int PRO, int NSTAGE = 2, int PREC = 0, int KS = 1, int NP = 0>
 __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmParams p) {
   static_assert(NP == 0 || (PRO != 3 && KS == 1), "NP: no residual-add prologue, no in-workgroup K split");
   static_assert(NP != 2 || AM != 2, "NP 2 (per-tap offsets) is for the k-contiguous A operand");
+  static_assert(NP != 3 || AM == 2, "NP 3 (pixel walk) is for the weight gradient's gathered operand");
   using Cfg = DjIgemmCfg<BM, BN, WM, WN, AM, BMD>;
   constexpr int TM = Cfg::TM, TN = Cfg::TN, NA = Cfg::NA, NB = Cfg::NB;
   constexpr int LDA_S = Cfg::LDA_S, LDB_S = Cfg::LDB_S;
@@ -175,12 +182,35 @@ __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmPa
         a2_sh[i] = dj_buf_ld4(rT, a2_ok[i] ? (unsigned)a2_c[i] * 4u : DJ_OOB);
       }
       row_valid |= a2_ok[i] ? (1u << i) : 0u;
-      if (NP) a2_c[i] = a2_ok[i] ? a2_c[i] * 4 : (int)0x80000000;    // byte offset of the chunk inside its pixel
+      if (NP == 1) a2_c[i] = a2_ok[i] ? a2_c[i] * 4 : (int)0x80000000;    // byte offset of the chunk inside its pixel
     }
   }
   // NP, A-mode 2: byte offset of this thread's pixel row (pixel kbeg + ar0 of the first K-step), advanced per K-step
-  int np_row = (NP && AM == 2) ? (kbeg + ar0) * p.ldsrc * 4 : 0;
+  int np_row = (NP == 1 && AM == 2) ? (kbeg + ar0) * p.ldsrc * 4 : 0;
   const int np_step = DJ_BK * p.ldsrc * 4;
+  // NP 3: this thread's output pixel (walk_ow, walk_oh), its index walk_kp, and the byte offset walk_off of chunk 0 at
+  // the tapped input pixel; walk_c0/1/2: what a K-step, a row carry and an image carry add to that offset
+  int walk_ow = 0, walk_oh = 0, walk_kp = 0, walk_off = 0;
+  int walk_sw = 0, walk_sh = 0, walk_c0 = 0, walk_c1 = 0, walk_c2 = 0, walk_dh = 0, walk_dw = 0;
+  if (NP == 3) {
+    const int tap = m0 / p.srcC, cb = m0 - tap * p.srcC;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    walk_dh = kh * p.dH - p.pT;
+    walk_dw = kw * p.dW - p.pL;
+    const int hw = p.rowH * p.rowW;
+    const int s_img = KSTEP / hw, r = KSTEP - s_img * hw;
+    walk_sh = r / p.rowW;
+    walk_sw = r - walk_sh * p.rowW;
+    const int pix4 = p.ldsrc * 4;
+    walk_c0 = ((s_img * p.srcH + walk_sh * p.sH) * p.srcW + walk_sw * p.sW) * pix4;
+    walk_c1 = (p.sH * p.srcW - p.rowW * p.sW) * pix4;
+    walk_c2 = (p.srcH - p.rowH * p.sH) * p.srcW * pix4;
+    walk_kp = kbeg + ar0;
+    const int img = walk_kp / hw, rem = walk_kp - img * hw;
+    walk_oh = rem / p.rowW;
+    walk_ow = rem - walk_oh * p.rowW;
+    walk_off = ((img * p.srcH + walk_oh * p.sH + walk_dh) * p.srcW + walk_ow * p.sW + walk_dw) * pix4 + (cb + 4 * ac) * 4;
+  }
   int b_off[NB];
   bool b_ok[NB];
   if (BMD == 0) {
@@ -288,11 +318,28 @@ __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmPa
         if (PRO == 3) R.ra2[j] = dj_buf_ld4(rA2, ok ? (unsigned)(a2_off[j] + t_c0 * 4) : DJ_OOB);
         a_valid |= ok ? (1u << j) : 0u;
       }
-    } else if (NP) {
+    } else if (NP == 1) {
       a_valid = row_valid;
 #pragma unroll
       for (int i = 0; i < NA; ++i) ra[i] = dj_buf_ld4(rA, (unsigned)(np_row + a2_c[i]));
       np_row += np_step;
+    } else if (NP == 3) {
+      // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): coordinates and strides are far below 2^23
+      const int ih = __mul24(walk_oh, p.sH) + walk_dh, iw = __mul24(walk_ow, p.sW) + walk_dw;
+      const bool ok = live & (walk_kp < kend) & ((unsigned)ih < (unsigned)p.srcH) & ((unsigned)iw < (unsigned)p.srcW);
+      const unsigned voff = ok ? (unsigned)walk_off : 0x80000000u;   // stays out of range with the chunk offsets added
+      a_valid = ok ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) ra[i] = dj_buf_ld4(rA, voff + 128u * i);
+      // on to the pixel KSTEP further: s_w < W and s_h < H, so each carry is at most one
+      walk_kp += KSTEP;
+      walk_ow += walk_sw;
+      const bool c1 = walk_ow >= p.rowW;
+      walk_ow -= c1 ? p.rowW : 0;
+      walk_oh += walk_sh + (c1 ? 1 : 0);
+      const bool c2 = walk_oh >= p.rowH;
+      walk_oh -= c2 ? p.rowH : 0;
+      walk_off += walk_c0 + (c1 ? walk_c1 : 0) + (c2 ? walk_c2 : 0);
     } else {
       a_valid = 0;
       const int kp = kcur + ar0;
@@ -360,11 +407,15 @@ __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmPa
         if (PRO == 3) v += R.ra2[j] * R.psc2 + R.psh2;
         // NP weight gradient: nothing to zero -- a chunk past M has zero scale AND shift (out-of-range loads), a pixel
         // past the chunk meets a zero dy row
-        bool ok = (NP && AM == 2) ? true : (bool)((a_valid >> j) & 1u);
-        v.x = ok ? fmaxf(v.x, relu_floor) : 0.f;
-        v.y = ok ? fmaxf(v.y, relu_floor) : 0.f;
-        v.z = ok ? fmaxf(v.z, relu_floor) : 0.f;
-        v.w = ok ? fmaxf(v.w, relu_floor) : 0.f;
+        // ReLU and the zeroing of out-of-bounds chunks in ONE v_med3 per value: clamp to [floor, +inf] in bounds, to
+        // [0, 0] outside (max + select were two of the three vector instructions per value here, and on the fp32
+        // matrix pipe every one of them is exposed)
+        bool ok = (NP == 1 && AM == 2) ? true : (bool)((a_valid >> j) & 1u);
+        const float lo = ok ? relu_floor : 0.f, hi = ok ? INFINITY : 0.f;
+        v.x = __builtin_amdgcn_fmed3f(v.x, lo, hi);
+        v.y = __builtin_amdgcn_fmed3f(v.y, lo, hi);
+        v.z = __builtin_amdgcn_fmed3f(v.z, lo, hi);
+        v.w = __builtin_amdgcn_fmed3f(v.w, lo, hi);
         ra[j] = v;
         if (PRO == 3 && store_sum)
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rY,

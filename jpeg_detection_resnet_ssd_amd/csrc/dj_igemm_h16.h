@@ -263,10 +263,11 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
         v = v * sc + sh;
         if (PRO == 3) v += ra2[j] * psc2 + psh2;
         bool ok = (a_valid >> j) & 1u;
-        v.x = ok ? fmaxf(v.x, relu_floor) : 0.f;
-        v.y = ok ? fmaxf(v.y, relu_floor) : 0.f;
-        v.z = ok ? fmaxf(v.z, relu_floor) : 0.f;
-        v.w = ok ? fmaxf(v.w, relu_floor) : 0.f;
+        const float lo = ok ? relu_floor : 0.f, hi = ok ? INFINITY : 0.f;   // ReLU + out-of-bounds zero: one v_med3
+        v.x = __builtin_amdgcn_fmed3f(v.x, lo, hi);
+        v.y = __builtin_amdgcn_fmed3f(v.y, lo, hi);
+        v.z = __builtin_amdgcn_fmed3f(v.z, lo, hi);
+        v.w = __builtin_amdgcn_fmed3f(v.w, lo, hi);
         if (PRO == 3 && store_sum)
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rY,
                                                  ok ? (int)(y_off[j] + pro_c0 * 4) : (int)DJ_OOB, 0, 0);

@@ -165,6 +165,9 @@ VARIANT_CASES = [
     (3, 19, 19, 128, 96, 3, 1, "same", 1),      # LDS-free wgrad, scalar-addressed form: one tap per wave tile, odd pixel count
     (3, 19, 19, 256, 40, 3, 1, "same", 2),      # ... dilation 2, N not a multiple of 32
     (5, 7, 9, 128, 64, 1, 1, "valid", 1),       # ... 1x1 (no padding tests), 315 pixels
+    (2, 11, 13, 128, 64, 3, 2, "same", 1),      # pixel-walk wgrad (in_c % BM == 0): stride 2, output grid != input grid
+    (7, 3, 3, 128, 64, 3, 1, "same", 1),        # ... a map smaller than a K-step (9 pixels): image carries every step
+    (3, 9, 5, 256, 32, 3, 2, "valid", 1),       # ... stride 2 without padding, 4x2 outputs per image
 ]
 
 
