@@ -382,11 +382,14 @@ class Conv2D(Layer):
         stats = fused_bn = None
         consumers = model.consumers_of(self.outbound[0])
         bn_consumer = (plan.training and not relu and len(consumers) == 1 and isinstance(consumers[0], BatchNormalization))
-        # Fewer 64x64 output tiles than CUs (the 5x5 / 10x10 stages at batch 32): such a GEMM only fills the chip when its
-        # reduction is split over workgroups, and a split launch cannot take the BatchNormalization statistics in its
+        # Fewer than two 64x64 output tiles per CU (the 5x5 / 10x10 stages at batch 32): such a GEMM only fills the chip
+        # evenly when its reduction is split over workgroups (400 equal tiles on 256 CUs: 144 CUs carry two, the launch
+        # takes two tile times for 1.56 of work), and a split launch cannot take the BatchNormalization statistics in its
         # epilogue (every workgroup holds a partial sum).  There the statistics come from one short column pass over the
         # (small) result instead -- dj_colstats_partial, what BatchNormalization.lower emits without conv statistics.
-        few_tiles = (-(-(b * desc.out_h * desc.out_w) // 64)) * (-(-self.filters // 64)) < 256
+        # Same box, deconv B=32: limit 256 -> 25.08 ms, 512..700 -> 24.94, 1500 -> 25.12.
+        tile_limit = int(os.environ.get("DJ_SPLIT_SMALL_BN_TILES", "512"))
+        few_tiles = (-(-(b * desc.out_h * desc.out_w) // 64)) * (-(-self.filters // 64)) < tile_limit
         split_instead = bn_consumer and few_tiles and os.environ.get("DJ_SPLIT_SMALL_BN", "1") != "0"
         if bn_consumer and not split_instead:
             if os.environ.get("DJ_FUSE_BNFIN", "0") == "1":
