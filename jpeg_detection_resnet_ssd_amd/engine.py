@@ -251,6 +251,7 @@ class Plan(object):
         self.side_stream = None
         self.side_enabled = True     # cleared while kernels are timed one by one (bench.py)
         self._side_dirty = False
+        self._side_joined = {}       # completion events of side-stream forward work the main stream already waits for
         if training and device.type == "cuda" and os.environ.get("DJ_SIDE_WGRAD", "1") != "0":
             self.side_stream = _side_stream(device)
             self._join_event = torch.cuda.Event()
@@ -297,13 +298,70 @@ class Plan(object):
     def emit_bwd(self, fn):
         self.bwd.append(fn)
 
-    def emit_conv(self, direction, desc, fn, backward=False, side=False):
+    # ---- forward work beside the main chain ------------------------------------------------------------------------
+    # The predictor heads of an SSD source (pack copy, one GEMM, unpack copies) and the L2Normalization in front of the
+    # first one only feed the prediction assembly at the very end of the forward pass, while the main stream goes on
+    # with the next feature layers -- small, latency-bound launches that leave most CUs idle.  Such work is issued on
+    # the side stream behind an event recorded when its input became final (`mark_ready`), and whoever consumes its
+    # results on the main stream waits for `side_done` first (`wait_side_inputs`, called for every layer).
+    def forward_side_ok(self, v):
+        return (self.side_stream is not None and getattr(v, "ready_event", None) is not None
+                and os.environ.get("DJ_SIDE_HEADS", "1") != "0")
+
+    def mark_ready(self, v):
+        """Record, at this point of the forward list, an event that says `v.buf` is final."""
+        if self.side_stream is None or getattr(v, "ready_event", None) is not None:
+            return
+        ev = torch.cuda.Event()
+        v.ready_event = ev
+        self.fwd.append(lambda: ev.record())
+
+    def emit_side(self, fn, after):
+        """Forward launch(es) `fn` on the side stream once event `after` has passed."""
+        side = self.side_stream
+
+        def run():
+            if not self.side_enabled:
+                return fn()
+            side.wait_event(after)
+            with torch.cuda.stream(side):
+                fn()
+        self.fwd.append(run)
+
+    def side_results(self, values):
+        """The Values in `values` were written by emit_side launches issued so far: record their completion."""
+        done = torch.cuda.Event()
+        side = self.side_stream
+
+        def rec():
+            if self.side_enabled:
+                done.record(side)
+        self.fwd.append(rec)
+        for v in values:
+            v.side_done = done
+
+    def wait_side_inputs(self, values):
+        """Main stream: wait for side-stream producers of `values` (once per producer event)."""
+        for v in values:
+            done = getattr(v, "side_done", None)
+            if done is None or id(done) in self._side_joined:
+                continue
+            self._side_joined[id(done)] = done
+
+            def wait(done=done):
+                if self.side_enabled:
+                    torch.cuda.current_stream().wait_event(done)
+            self.fwd.append(wait)
+
+    def emit_conv(self, direction, desc, fn, backward=False, side=False, fwd_after=None):
         """Record one implicit-GEMM launch (direction 0 fwd / 1 dgrad / 2 wgrad, +4 = forward with BN statistics).
         side=True: the launch has no consumer before the optimizer / gradient exchange and every buffer it reads is
         final when it is issued, so it may run on the plan's side stream."""
         self.conv_calls.append((direction, desc, fn))
         if side and backward and self.side_stream is not None:
             fn = self._on_side(fn)
+        if fwd_after is not None and not backward:
+            return self.emit_side(fn, fwd_after)
         (self.bwd if backward else self.fwd).append(fn)
 
     def _on_side(self, fn):

@@ -287,6 +287,14 @@ class Conv2D(Layer):
             return [self]
         return sibs
 
+    def runs_beside(self, plan, model, ins):
+        """True when this layer's forward launches go to the side stream (fused predictor heads whose input carries a
+        `ready_event`): Model._plan then does not make the main stream wait for side-stream producers of its inputs."""
+        if id(self) in plan.fused_outputs:
+            return True
+        x = ins[0]
+        return plan.forward_side_ok(x) and len(self._fusable_siblings(model, x)) > 1
+
     def _lower_fused(self, plan, model, x, sibs):
         """One forward GEMM, one input-gradient GEMM and one weight-gradient GEMM for all of `sibs`: their kernels are
         packed side by side into Wp[kh, kw, Cin, Np] (Np = total filters rounded up to 32, padding columns zero) by one
@@ -312,11 +320,16 @@ class Conv2D(Layer):
                                l.filters, 0))
             pack_parts.append((l.bias.param.view(1, l.filters), l.filters, bias_p.view(1, n_pad)[:, off:off + l.filters],
                                n_pad, 1, l.filters, 0))
-        plan.emit(engine.copy2d_multi(pack_parts))
+        # beside the main chain when the input's readiness is known (engine.Plan.emit_side): the heads only feed the
+        # prediction assembly at the end of the forward pass
+        after = x.ready_event if plan.forward_side_ok(x) else None
+        emit = (lambda fn: plan.emit_side(fn, after)) if after is not None else plan.emit
+        emit(engine.copy2d_multi(pack_parts))
         y_zeroed = (engine.tuned_splits(0, desc) or 1) > 1 and os.environ.get("DJ_ZERO_ARENA", "1") != "0"
         y_p = (plan.zeroed_each_step if y_zeroed else plan.empty)(b, desc.out_h, desc.out_w, n_pad)
         xbuf = x.buf
-        plan.emit_conv(0, desc, lambda: Kn.conv2d_fwd(desc, xbuf, wp, bias_p, y_p, None, None, False, False, None, y_zeroed))
+        plan.emit_conv(0, desc, lambda: Kn.conv2d_fwd(desc, xbuf, wp, bias_p, y_p, None, None, False, False, None, y_zeroed),
+                       fwd_after=after)
         y_p2 = y_p.view(rows, n_pad)
         outs, unpack = [], []
         for l, off in zip(sibs, offs):
@@ -325,7 +338,9 @@ class Conv2D(Layer):
             v = Value(y, needs_grad=True, name=l.name)
             outs.append(v)
             plan.fused_outputs[id(l)] = v
-        plan.emit(engine.copy2d_multi(unpack))
+        emit(engine.copy2d_multi(unpack))
+        if after is not None:
+            plan.side_results(outs)
 
         def build_backward():
             live = [(l, off, v) for l, off, v in zip(sibs, offs, outs) if v.grad is not None]
@@ -425,6 +440,7 @@ class Conv2D(Layer):
                 plan.emit_conv(4 if stats is not None else 0, desc,
                                lambda: Kn.conv2d_fwd_addrelu(desc, zb, wgt, bias, y, zs, zt, rb, rs, rt, xbuf, relu, stats))
             x.pending_add = None
+            plan.mark_ready(x)     # the sum exists from here on: its other readers may run beside the main chain
         elif fused_bn is not None:
             plan.emit_conv(4, desc, lambda: Kn.conv2d_fwd_bn(desc, xbuf, wgt, bias, y, bn_arg, pro[0], pro[1], pro[2]))
         else:

@@ -273,8 +273,15 @@ class Model(object):
             if isinstance(lyr, L.InputLayer):
                 if not any(lyr is t.layer for t in self.inputs):
                     raise ValueError("Input layer %s is not a model input" % lyr.name)
+            if not (hasattr(lyr, "runs_beside") and lyr.runs_beside(plan, self, lyr_ins)):
+                plan.wait_side_inputs(lyr_ins)
             out = lyr.lower(plan, self, lyr_ins)
             plan.values[id(lyr.outbound[0])] = out
+            # a tensor with several readers may have some that only feed the end of the forward pass (SSD predictor
+            # heads): note the point where it is final, so that they can run beside the main chain (Plan.emit_side)
+            if (training and isinstance(out, Value) and len(self.consumers_of(lyr.outbound[0])) > 1
+                    and getattr(out, "pending_add", None) is None and getattr(out, "side_done", None) is None):
+                plan.mark_ready(out)
         # model inputs in the order given to Model(...)
         order = []
         for t in self.inputs:

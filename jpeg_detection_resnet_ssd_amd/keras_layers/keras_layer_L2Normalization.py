@@ -29,6 +29,15 @@ class L2Normalization(Layer):
         base_config = super(L2Normalization, self).get_config()
         return dict(list(base_config.items()) + list(config.items()))
 
+    def runs_beside(self, plan, model, ins):
+        """Forward launch on the side stream (engine.Plan.emit_side) when every reader is a predictor head that runs there."""
+        x = ins[0]
+        if not plan.forward_side_ok(x) or x.is_affine or getattr(x, "pending_add", None) is not None:
+            return False
+        users = model.consumers_of(self.outbound[0])
+        from ..keras.layers import Conv2D
+        return bool(users) and all(type(u) is Conv2D and u.activation is None for u in users)
+
     def lower(self, plan, model, ins):
         x = ins[0]
         xbuf = _materialised(x, self.name, plan)
@@ -36,8 +45,14 @@ class L2Normalization(Layer):
         y = plan.empty(*xbuf.shape)
         rnorm = plan.empty(rows)
         gamma = self.gamma.param
-        plan.emit(lambda: call("dj_l2norm_fwd", xbuf, ldx, gamma, y, c, rnorm, rows, c))
         out = Value(y, needs_grad=True, name=self.name)
+        if self.runs_beside(plan, model, ins) and xbuf is x.buf:
+            # only predictor heads read this: normalise beside the main chain, in front of them on the side stream
+            plan.emit_side(lambda: call("dj_l2norm_fwd", xbuf, ldx, gamma, y, c, rnorm, rows, c), x.ready_event)
+            out.ready_event = x.ready_event     # the heads queue behind this launch on the same stream
+            plan.side_results([out])
+        else:
+            plan.emit(lambda: call("dj_l2norm_fwd", xbuf, ldx, gamma, y, c, rnorm, rows, c))
 
         def build_backward():
             if out.grad is None:
