@@ -65,14 +65,33 @@ int dj_conv2d_fwd_stats_rows(const dj_conv2d_desc* d);
  * all zeros on entry, so a split-K launch (atomic accumulation) does not clear it first. */
 #define DJ_CONV_RELU 1
 #define DJ_CONV_Y_ZEROED 2
+#define DJ_CONV_STATS_MAY_SPLIT 4 /* dj_conv2d_nhwc_fwd_ws only, see there */
 int dj_conv2d_nhwc_fwd(const dj_conv2d_desc* d, const float* x, const float* w, const float* bias,
                        float* y, const float* pro_scale, const float* pro_shift, int pro_relu,
                        int relu, float* stats, void* stream);
 
+/* dj_conv2d_nhwc_fwd with a caller-owned workspace (the reference's TF convolution is bit-reproducible in the forward
+ * pass, L/models/keras_ssd300_dct_j2d_resnet.py:481-675 are the small-map layers this matters for): when the tuned
+ * launch splits its reduction over workgroups and `workspace_floats` >= dj_conv2d_fwd_workspace_floats(d, ...), the K
+ * chunks store their partial tiles to the workspace and a second kernel adds them in a fixed order, adds the bias,
+ * applies ReLU and -- if `stats` is given -- takes the BatchNormalization statistics of the sum; without (enough)
+ * workspace the launch accumulates with fp32 atomics in arrival order like dj_conv2d_nhwc_fwd.
+ * DJ_CONV_STATS_MAY_SPLIT in `relu`: a launch with `stats` is tuned like one without and may be split (its statistics
+ * then come from the reduction); otherwise a launch with `stats` is never split. */
+int dj_conv2d_nhwc_fwd_ws(const dj_conv2d_desc* d, const float* x, const float* w, const float* bias,
+                          float* y, const float* pro_scale, const float* pro_shift, int pro_relu,
+                          int relu, float* stats, float* workspace, long workspace_floats, void* stream);
+/* floats of workspace that make the CURRENT tuning choice for this geometry run without atomics (0: not split; < 0: bad
+ * descriptor) */
+long dj_conv2d_fwd_workspace_floats(const dj_conv2d_desc* d, int may_split_stats);
+
 /* dx (+)= conv_transpose(dy, w) [+ bias].  Gradient of Conv2D w.r.t. its input (TF
  * Conv2DBackpropInput); with `bias` it is also the forward of keras.layers.Conv2DTranspose
  * (L/models/...resnet.py:1709-1711), whose (kh,kw,out,in) kernel is the HWIO kernel of
- * the convolution it transposes.  beta=1 accumulates into dx. */
+ * the convolution it transposes.  beta: bit 0 = accumulate into dx; DJ_DGRAD_NO_SPLIT = never split the reduction over
+ * workgroups (a split launch adds with fp32 atomics in arrival order; the forward use as Conv2DTranspose sets it so that
+ * the forward pass stays bit-reproducible). */
+#define DJ_DGRAD_NO_SPLIT 2
 int dj_conv2d_nhwc_dgrad(const dj_conv2d_desc* d, const float* dy, const float* w, const float* bias,
                          float* dx, int beta, void* stream);
 
@@ -88,6 +107,11 @@ int dj_conv2d_nhwc_fwd_addrelu(const dj_conv2d_desc* d, const float* x, const fl
                                const float* pro_scale, const float* pro_shift, const float* res, int ld_res,
                                const float* res_scale, const float* res_shift, float* sum_out, int ld_sum, int relu,
                                float* stats, void* stream);
+/* ... with the split-K workspace of dj_conv2d_nhwc_fwd_ws (same rules, same size query) */
+int dj_conv2d_nhwc_fwd_addrelu_ws(const dj_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y,
+                                  const float* pro_scale, const float* pro_shift, const float* res, int ld_res,
+                                  const float* res_scale, const float* res_shift, float* sum_out, int ld_sum, int relu,
+                                  float* stats, float* workspace, long workspace_floats, void* stream);
 
 /* Convolution + the training-mode BatchNormalization that follows it (keras BatchNormalization(axis=3) after Conv2D,
  * L/models/keras_ssd300_dct_j2d_resnet.py:66-99): the conv epilogue adds each tile's column sums / sums of squares to

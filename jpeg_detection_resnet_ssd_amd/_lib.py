@@ -66,11 +66,15 @@ SIGNATURES = {
     "dj_abi_version": (c_int, []),
     "dj_conv2d_fwd_stats_rows": (c_int, [POINTER(ConvDesc)]),
     "dj_conv2d_nhwc_fwd": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, FP, c_int, c_int, FP, c_void_p]),
+    "dj_conv2d_nhwc_fwd_ws": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, FP, c_int, c_int, FP, FP, c_long, c_void_p]),
+    "dj_conv2d_fwd_workspace_floats": (c_long, [POINTER(ConvDesc), c_int]),
     "dj_conv2d_nhwc_dgrad": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, c_int, c_void_p]),
     "dj_conv2d_nhwc_wgrad": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, c_int, c_int, c_void_p]),
     "dj_conv2d_fwd_addrelu_supported": (c_int, [POINTER(ConvDesc)]),
     "dj_conv2d_nhwc_fwd_addrelu": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, FP, FP, c_int, FP, FP, FP, c_int, c_int, FP,
                                            c_void_p]),
+    "dj_conv2d_nhwc_fwd_addrelu_ws": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, FP, FP, c_int, FP, FP, FP, c_int, c_int,
+                                              FP, FP, c_long, c_void_p]),
     "dj_colsum_direct": (c_int, [FP, c_long, c_int, c_int, FP, c_int, c_void_p]),
     "dj_colsum_multi": (c_int, [POINTER(ColsumPart), c_int, c_void_p]),
     "dj_copy2d_multi": (c_int, [POINTER(CopyPart), c_int, c_void_p]),

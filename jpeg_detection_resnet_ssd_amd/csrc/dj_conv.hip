@@ -188,6 +188,102 @@ extern "C" int dj_conv2d_fwd_stats_rows(const dj_conv2d_desc* d) {
   return dj_cdiv((long)d->batch * d->out_h * d->out_w, 64);
 }
 
+// Second half of a split-K forward convolution without atomics: the K chunks left their partial tiles in `nsplit` slabs
+// [rows][N]; this pass adds them IN A FIXED ORDER (bit-reproducible, unlike fp32 atomics in arrival order), takes the
+// BatchNormalization column statistics of the sum (per 64 rows: [ceil(rows/64)][2][N], before the bias, as the GEMM
+// epilogue does), then adds bias / applies ReLU and writes y.  One workgroup per 64 rows x (16 * VEC) columns.
+template <int VEC>
+__global__ __launch_bounds__(256) void dj_splitk_reduce_kernel(const float* slabs, int nsplit, long slab_stride, long rows,
+                                                               int N, const float* bias, int relu, float* y, int ld_y,
+                                                               float* stats) {
+  // 16 column chunks (16 * VEC columns) x 16 row lanes; a thread owns rows ty, ty + 16, ty + 32, ty + 48 of the group
+  __shared__ float red[16][16][2 * VEC];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = (blockIdx.y * 16 + tx) * VEC;
+  const long r0 = (long)blockIdx.x * 64;
+  float s[VEC], q[VEC], b[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    s[v] = 0.f;
+    q[v] = 0.f;
+    b[v] = (bias && c + v < N) ? bias[c + v] : 0.f;
+  }
+  if (c < N) {
+    float a[4][VEC];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) a[j][v] = 0.f;
+    for (int k = 0; k < nsplit; ++k) {      // slabs in index order: the sum does not depend on who finished first
+      const float* slab = slabs + (long)k * slab_stride + c;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const long r = r0 + ty + 16 * j;
+        if (r < rows) {
+          if (VEC == 4) {
+            f32x4 t = *reinterpret_cast<const f32x4*>(slab + r * N);
+            a[j][0] += t.x;
+            a[j][1 % VEC] += t.y;
+            a[j][2 % VEC] += t.z;
+            a[j][3 % VEC] += t.w;
+          } else {
+            a[j][0] += slab[r * N];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long r = r0 + ty + 16 * j;
+      if (r >= rows) continue;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        s[v] += a[j][v];
+        q[v] += a[j][v] * a[j][v];
+        float o = a[j][v] + b[v];
+        a[j][v] = relu ? fmaxf(o, 0.f) : o;
+      }
+      float* dst = y + r * ld_y + c;
+      if (VEC == 4) *reinterpret_cast<f32x4*>(dst) = f32x4{a[j][0], a[j][1 % VEC], a[j][2 % VEC], a[j][3 % VEC]};
+      else dst[0] = a[j][0];
+    }
+  }
+  if (!stats) return;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    red[ty][tx][v] = s[v];
+    red[ty][tx][VEC + v] = q[v];
+  }
+  __syncthreads();
+  if (ty == 0 && c < N) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      float ss = 0.f, qq = 0.f;
+      for (int l = 0; l < 16; ++l) {     // fixed order over the row lanes
+        ss += red[l][tx][v];
+        qq += red[l][tx][VEC + v];
+      }
+      stats[((long)blockIdx.x * 2 + 0) * N + c + v] = ss;
+      stats[((long)blockIdx.x * 2 + 1) * N + c + v] = qq;
+    }
+  }
+}
+
+static int launch_splitk_reduce(const float* slabs, int nsplit, long slab_stride, long rows, int N, const float* bias,
+                                int relu, float* y, int ld_y, float* stats, hipStream_t s) {
+  const bool v4 = (N % 4 == 0) && (ld_y % 4 == 0) && aligned16(slabs) && aligned16(y) && (slab_stride % 4 == 0);
+  const int cols_per_block = v4 ? 64 : 16;
+  dim3 grid((unsigned)((rows + 63) / 64), (unsigned)((N + cols_per_block - 1) / cols_per_block));
+  if (v4)
+    hipLaunchKernelGGL(dj_splitk_reduce_kernel<4>, grid, dim3(256), 0, s, slabs, nsplit, slab_stride, rows, N, bias, relu, y,
+                       ld_y, stats);
+  else
+    hipLaunchKernelGGL(dj_splitk_reduce_kernel<1>, grid, dim3(256), 0, s, slabs, nsplit, slab_stride, rows, N, bias, relu, y,
+                       ld_y, stats);
+  DJ_CHECK_LAUNCH("dj_splitk_reduce_kernel");
+  return DJ_OK;
+}
+
 struct FwdResidual {
   const dj_bn_train* bn = nullptr;   // finish the following BatchNormalization inside the launch
   const float* res = nullptr;
@@ -200,7 +296,7 @@ struct FwdResidual {
 
 static int conv_fwd_impl(const dj_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y,
                          const float* pro_scale, const float* pro_shift, int pro_relu, int relu, float* stats,
-                         const FwdResidual& rz, void* stream) {
+                         const FwdResidual& rz, void* stream, float* ws = nullptr, long ws_floats = 0) {
   if (int rc = check_desc(d)) return rc;
   DJ_CHECK_ARG(x && w && y, "conv fwd: null tensor");
   DJ_CHECK_ARG((pro_scale == nullptr) == (pro_shift == nullptr), "conv fwd: pro_scale/pro_shift must come together");
@@ -229,6 +325,7 @@ static int conv_fwd_impl(const dj_conv2d_desc* d, const float* x, const float* w
   p.ldc = d->ld_y;
   p.cmap = 0;
   const bool y_zeroed = (relu & DJ_CONV_Y_ZEROED) != 0;
+  const bool stats_may_split = (relu & DJ_CONV_STATS_MAY_SPLIT) != 0 && stats != nullptr && ws != nullptr && !rz.bn;
   relu &= DJ_CONV_RELU;
   p.relu = relu;
   p.vecA = (d->in_c % 4 == 0) && (d->ld_x % 4 == 0) && aligned16(x) &&
@@ -269,14 +366,29 @@ static int conv_fwd_impl(const dj_conv2d_desc* d, const float* x, const float* w
     p.bn_momentum = b.momentum;
     p.bn_count = (double)p.M;
   }
-  const bool wants_stats = stats != nullptr || rz.bn != nullptr;
+  // statistics come out of the GEMM epilogue (one K range per tile) -- or, for a caller that allows it and supplies a
+  // workspace, out of the slab reduction of a split launch (tuned like a launch without statistics)
+  const bool wants_stats = (stats != nullptr || rz.bn != nullptr) && !stats_may_split;
   int splits = 1;
   int cfg = choose_cfg(p.M, p.N, p.K, !wants_stats, &splits);
   tune_lookup(wants_stats ? 4 : 0, d, &cfg, &splits);
   if (wants_stats) splits = 1;
   p.kchunk = dj_cdiv(dj_cdiv(p.K, splits), DJ_BK) * DJ_BK;
   splits = dj_cdiv(p.K, p.kchunk);
-  if (splits > 1) {
+  // split-K through slabs in the caller's workspace + a fixed-order reduction (deterministic), when they fit
+  bool slabs = splits > 1 && ws != nullptr && !rz.bn && (long)splits * p.M * p.N <= ws_floats && aligned16(ws);
+  if (splits > 1 && !slabs && stats_may_split) {   // statistics cannot come from atomics: one K range after all
+    splits = 1;
+    p.kchunk = dj_cdiv(p.K, DJ_BK) * DJ_BK;
+  }
+  if (slabs) {
+    p.C = ws;
+    p.ldc = p.N;
+    p.slab_stride = (long)p.M * p.N;
+    p.bias = nullptr;
+    p.relu = 0;
+    p.stats = nullptr;
+  } else if (splits > 1) {
     p.atomic = 1;
     p.relu = 0;
     if (!y_zeroed) {
@@ -292,6 +404,7 @@ static int conv_fwd_impl(const dj_conv2d_desc* d, const float* x, const float* w
                                            "(channels %% 32, 16-byte aligned tensors)");
   }
   if (int rc = dj_launch_cfg<0, 0>(cfg, p, splits, s)) return rc;
+  if (slabs) return launch_splitk_reduce(ws, splits, p.slab_stride, p.M, p.N, bias, relu, y, d->ld_y, stats, s);
   if (splits > 1 && relu) {
     long total = (long)p.M * p.N;
     int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
@@ -305,6 +418,32 @@ extern "C" int dj_conv2d_nhwc_fwd(const dj_conv2d_desc* d, const float* x, const
                                   float* y, const float* pro_scale, const float* pro_shift, int pro_relu, int relu,
                                   float* stats, void* stream) {
   return conv_fwd_impl(d, x, w, bias, y, pro_scale, pro_shift, pro_relu, relu, stats, FwdResidual(), stream);
+}
+
+// As dj_conv2d_nhwc_fwd, with a caller-owned workspace of `workspace_floats` floats (dj_conv2d_fwd_workspace_floats): a
+// split-K launch then writes its partial tiles there and a fixed-order reduction produces y -- bit-reproducible, where
+// the version without workspace accumulates with fp32 atomics in arrival order.  With DJ_CONV_STATS_MAY_SPLIT in `relu`
+// a launch with `stats` may be split too (the reduction takes the statistics).
+extern "C" int dj_conv2d_nhwc_fwd_ws(const dj_conv2d_desc* d, const float* x, const float* w, const float* bias,
+                                     float* y, const float* pro_scale, const float* pro_shift, int pro_relu, int relu,
+                                     float* stats, float* workspace, long workspace_floats, void* stream) {
+  DJ_CHECK_ARG(workspace_floats >= 0 && (workspace != nullptr || workspace_floats == 0), "conv fwd: bad workspace");
+  return conv_fwd_impl(d, x, w, bias, y, pro_scale, pro_shift, pro_relu, relu, stats, FwdResidual(), stream, workspace,
+                       workspace_floats);
+}
+
+// Floats of workspace with which dj_conv2d_nhwc_fwd_ws runs this geometry without atomics under the CURRENT tuning
+// choice (0: the launch is not split).  may_split_stats: as the flag of the same name.
+extern "C" long dj_conv2d_fwd_workspace_floats(const dj_conv2d_desc* d, int may_split_stats) {
+  if (check_desc(d)) return -1;
+  const int M = d->batch * d->out_h * d->out_w, N = d->out_c, K = d->kernel_h * d->kernel_w * d->in_c;
+  int splits = 1;
+  int cfg = choose_cfg(M, N, K, true, &splits);
+  tune_lookup(0, d, &cfg, &splits);
+  (void)may_split_stats;
+  const int kchunk = dj_cdiv(dj_cdiv(K, splits), DJ_BK) * DJ_BK;
+  splits = dj_cdiv(K, kchunk);
+  return splits > 1 ? (long)splits * M * N : 0;
 }
 
 // Forward conv whose only consumer is a training-mode BatchNormalization: that layer's statistics, scale/shift and
@@ -343,10 +482,10 @@ extern "C" int dj_conv2d_fwd_addrelu_supported(const dj_conv2d_desc* d) {
          d->out_c % 4 == 0;
 }
 
-extern "C" int dj_conv2d_nhwc_fwd_addrelu(const dj_conv2d_desc* d, const float* x, const float* w, const float* bias,
-                                          float* y, const float* pro_scale, const float* pro_shift, const float* res,
-                                          int ld_res, const float* res_scale, const float* res_shift, float* sum_out,
-                                          int ld_sum, int relu, float* stats, void* stream) {
+static int conv_fwd_addrelu_impl(const dj_conv2d_desc* d, const float* x, const float* w, const float* bias,
+                                 float* y, const float* pro_scale, const float* pro_shift, const float* res,
+                                 int ld_res, const float* res_scale, const float* res_shift, float* sum_out,
+                                 int ld_sum, int relu, float* stats, float* ws, long ws_floats, void* stream) {
   DJ_CHECK_ARG(d && dj_conv2d_fwd_addrelu_supported(d), "conv fwd (residual add): needs a 1x1 stride-1 unpadded conv with "
                                                          "in_c %% 32 == 0");
   DJ_CHECK_ARG(res && pro_scale && pro_shift, "conv fwd (residual add): res, pro_scale and pro_shift are required");
@@ -362,13 +501,34 @@ extern "C" int dj_conv2d_nhwc_fwd_addrelu(const dj_conv2d_desc* d, const float* 
   rz.res_shift = res_shift;
   rz.sum_out = sum_out;
   rz.ld_sum = ld_sum;
-  return conv_fwd_impl(d, x, w, bias, y, pro_scale, pro_shift, 1, relu, stats, rz, stream);
+  return conv_fwd_impl(d, x, w, bias, y, pro_scale, pro_shift, 1, relu, stats, rz, stream, ws, ws_floats);
+}
+
+extern "C" int dj_conv2d_nhwc_fwd_addrelu(const dj_conv2d_desc* d, const float* x, const float* w, const float* bias,
+                                          float* y, const float* pro_scale, const float* pro_shift, const float* res,
+                                          int ld_res, const float* res_scale, const float* res_shift, float* sum_out,
+                                          int ld_sum, int relu, float* stats, void* stream) {
+  return conv_fwd_addrelu_impl(d, x, w, bias, y, pro_scale, pro_shift, res, ld_res, res_scale, res_shift, sum_out, ld_sum,
+                               relu, stats, nullptr, 0, stream);
+}
+
+// dj_conv2d_nhwc_fwd_addrelu with the split-K workspace of dj_conv2d_nhwc_fwd_ws (same rules, same size query)
+extern "C" int dj_conv2d_nhwc_fwd_addrelu_ws(const dj_conv2d_desc* d, const float* x, const float* w, const float* bias,
+                                             float* y, const float* pro_scale, const float* pro_shift, const float* res,
+                                             int ld_res, const float* res_scale, const float* res_shift, float* sum_out,
+                                             int ld_sum, int relu, float* stats, float* workspace, long workspace_floats,
+                                             void* stream) {
+  DJ_CHECK_ARG(workspace_floats >= 0 && (workspace != nullptr || workspace_floats == 0), "conv fwd (residual add): bad workspace");
+  return conv_fwd_addrelu_impl(d, x, w, bias, y, pro_scale, pro_shift, res, ld_res, res_scale, res_shift, sum_out, ld_sum,
+                               relu, stats, workspace, workspace_floats, stream);
 }
 
 extern "C" int dj_conv2d_nhwc_dgrad(const dj_conv2d_desc* d, const float* dy, const float* w, const float* bias,
                                     float* dx, int beta, void* stream) {
   if (int rc = check_desc(d)) return rc;
   DJ_CHECK_ARG(dy && w && dx, "conv dgrad: null tensor");
+  const bool one_k_range = (beta & DJ_DGRAD_NO_SPLIT) != 0;   // no split-K: no arrival-order arithmetic
+  beta &= 1;
   hipStream_t s = (hipStream_t)stream;
   DjIgemmParams p;
   memset(&p, 0, sizeof(p));
@@ -430,6 +590,7 @@ extern "C" int dj_conv2d_nhwc_dgrad(const dj_conv2d_desc* d, const float* dy, co
   p.cmap = 0;
   int cfg = choose_cfg(p.M, p.N, p.K, true, &splits);
   tune_lookup(1, d, &cfg, &splits);
+  if (one_k_range) splits = 1;
   p.kchunk = dj_cdiv(dj_cdiv(p.K, splits), DJ_BK) * DJ_BK;
   splits = dj_cdiv(p.K, p.kchunk);
   if (splits > 1) {

@@ -47,6 +47,7 @@ struct DjIgemmParams {
   int relu;                // epilogue ReLU
   int beta;                // 1: C = acc + C
   int atomic;              // 1: atomicAdd into C (split-K)
+  long slab_stride;        // != 0: split-K WITHOUT atomics -- K-chunk blockIdx.y stores its partial tile to C + blockIdx.y * slab_stride
   int vecA, vecB;          // 16-byte loads legal for A / B
   float inv_rowHW, inv_rowW;  // 1/(rowH*rowW), 1/rowW for the pixel decomposition of the fast wgrad path
   int a_bytes, b_bytes;       // byte extents of A and B for the buffer descriptors of the fast path
@@ -246,6 +247,7 @@ __device__ __forceinline__ void dj_igemm_epilogue(const DjIgemmParams& p, f32x16
     }
   }
 
+  float* const Cb = p.C + (size_t)blockIdx.y * p.slab_stride;
   if (p.cmap == 0 && m0 + BM <= p.M && n0 + BN <= p.N) {
     float bv[TN];
     const bool add_bias = p.bias && (!p.atomic || blockIdx.y == 0);
@@ -253,7 +255,7 @@ __device__ __forceinline__ void dj_igemm_epilogue(const DjIgemmParams& p, f32x16
     for (int j = 0; j < TN; ++j) bv[j] = add_bias ? p.bias[n0 + (wn * TN + j) * 32 + l31] : 0.f;
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
     const int uwm = uwave / WN, uwn = uwave % WN;
-    float* ubase = p.C + (size_t)(m0 + uwm * TM * 32) * p.ldc + (n0 + uwn * TN * 32);
+    float* ubase = Cb + (size_t)(m0 + uwm * TM * 32) * p.ldc + (n0 + uwn * TN * 32);
     const unsigned lane_byte = (unsigned)(4 * lh * p.ldc + l31) * 4u;
     dj_store_full_tile<TM, TN>(ubase, lane_byte, acc, bv, p.ldc, p.beta != 0 && !p.atomic, p.relu != 0 && !p.atomic, p.atomic != 0);
   } else {
@@ -278,7 +280,7 @@ __device__ __forceinline__ void dj_igemm_epilogue(const DjIgemmParams& p, f32x16
         int n = n0 + (wn * TN + j) * 32 + l31;
         if (n >= p.N) continue;
         float v = acc[i][j][r];
-        float* dst = p.C + rowoff + n;
+        float* dst = Cb + rowoff + n;
         if (p.atomic) {
           if (p.bias && blockIdx.y == 0) v += p.bias[n];
           atomicAdd(dst, v);

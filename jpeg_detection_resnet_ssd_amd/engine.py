@@ -99,6 +99,10 @@ def query(name, *args):
     return check(getattr(_lib.load(), name)(*[int(a) for a in args]), name)
 
 
+def query_long(name, desc, *args):
+    return check(getattr(_lib.load(), name)(desc, *[int(a) for a in args]), name)
+
+
 class _TunedByMode(dict):
     """conv geometry key -> (ms, cfg, splits) of the choices registered with the library, one table per arithmetic mode
     (the library keys its overrides by mode too): `_TUNED` behaves like the dict of the calling thread's current mode."""
@@ -221,6 +225,34 @@ class Value(object):
         return tuple(self.buf.shape)
 
 
+class _Workspace(object):
+    """One float buffer per (plan, stream), grown to the largest split-K slab set its convolutions need (capped: beyond
+    the cap a launch falls back to fp32 atomics, see include/dj_hip.h)."""
+    CAP_FLOATS = 64 << 20
+
+    def __init__(self, device):
+        self.device = device
+        self.users = []
+        # DJ_FWD_SLABS=0: no workspace -- split-K forward launches accumulate with fp32 atomics again (A/B runs)
+        self.off = os.environ.get("DJ_FWD_SLABS", "1") == "0"
+        self.buf = None if self.off else torch.empty(4, dtype=torch.float32, device=device)
+
+    def register(self, desc, stats_may_split):
+        if self.off:
+            return
+        self.users.append((desc, bool(stats_may_split)))
+        self._fit(desc, stats_may_split)
+
+    def _fit(self, desc, may):
+        need = min(int(query_long("dj_conv2d_fwd_workspace_floats", desc, int(may))), self.CAP_FLOATS)
+        if need > self.buf.numel():
+            self.buf = torch.empty(need, dtype=torch.float32, device=self.device)
+
+    def resize(self):
+        for desc, may in self.users:
+            self._fit(desc, may)
+
+
 class Plan(object):
     def __init__(self, device, batch_size, training):
         self.device = device
@@ -251,6 +283,7 @@ class Plan(object):
         self.side_stream = None
         self.side_enabled = True     # cleared while kernels are timed one by one (bench.py)
         self._side_dirty = False
+        self._workspaces = {}        # side? -> _Workspace (split-K slabs of the forward convolutions)
         self._side_joined = {}       # completion events of side-stream forward work the main stream already waits for
         if training and device.type == "cuda" and os.environ.get("DJ_SIDE_WGRAD", "1") != "0":
             self.side_stream = _side_stream(device)
@@ -290,6 +323,20 @@ class Plan(object):
         t = torch.zeros(*shape, dtype=torch.float32, device=self.device)
         self.bytes_allocated += t.numel() * 4
         return t
+
+    # ---- split-K workspaces of the forward convolutions ---------------------------------------------------------------
+    def conv_workspace(self, desc, side=False, stats_may_split=False):
+        """Holder of the workspace through which the forward convolutions issued on one stream (main / side) run their
+        split-K launches WITHOUT atomics (dj_conv2d_nhwc_fwd_ws: slabs + fixed-order reduction, bit-reproducible).
+        Sized for the current tuning choice of every registered geometry; `finalize_workspaces` sizes it again once the
+        tuner has had its say.  Launches on one stream are serial, so one buffer per stream serves them all."""
+        ws = self._workspaces.setdefault(bool(side), _Workspace(self.device))
+        ws.register(desc, stats_may_split)
+        return ws
+
+    def finalize_workspaces(self):
+        for ws in self._workspaces.values():
+            ws.resize()
 
     # ---- recording -------------------------------------------------------------
     def emit(self, fn):

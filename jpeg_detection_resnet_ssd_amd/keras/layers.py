@@ -325,11 +325,11 @@ class Conv2D(Layer):
         after = x.ready_event if plan.forward_side_ok(x) else None
         emit = (lambda fn: plan.emit_side(fn, after)) if after is not None else plan.emit
         emit(engine.copy2d_multi(pack_parts))
-        y_zeroed = (engine.tuned_splits(0, desc) or 1) > 1 and os.environ.get("DJ_ZERO_ARENA", "1") != "0"
-        y_p = (plan.zeroed_each_step if y_zeroed else plan.empty)(b, desc.out_h, desc.out_w, n_pad)
+        y_p = plan.empty(b, desc.out_h, desc.out_w, n_pad)
         xbuf = x.buf
-        plan.emit_conv(0, desc, lambda: Kn.conv2d_fwd(desc, xbuf, wp, bias_p, y_p, None, None, False, False, None, y_zeroed),
-                       fwd_after=after)
+        ws = plan.conv_workspace(desc, side=after is not None)     # split-K through slabs: no atomics, no cleared y
+        plan.emit_conv(0, desc, lambda: Kn.conv2d_fwd(desc, xbuf, wp, bias_p, y_p, None, None, False, False, None,
+                                                      workspace=ws.buf), fwd_after=after)
         y_p2 = y_p.view(rows, n_pad)
         outs, unpack = [], []
         for l, off in zip(sibs, offs):
@@ -400,14 +400,14 @@ class Conv2D(Layer):
         # Fewer than two 64x64 output tiles per CU (the 5x5 / 10x10 stages at batch 32): such a GEMM only fills the chip
         # evenly when its reduction is split over workgroups (400 equal tiles on 256 CUs: 144 CUs carry two, the launch
         # takes two tile times for 1.56 of work), and a split launch cannot take the BatchNormalization statistics in its
-        # epilogue (every workgroup holds a partial sum).  There the statistics come from one short column pass over the
-        # (small) result instead -- dj_colstats_partial, what BatchNormalization.lower emits without conv statistics.
+        # epilogue (every workgroup holds a partial sum).  There the statistics come from the fixed-order reduction of
+        # the split launch's slabs instead (dj_conv2d_nhwc_fwd_ws with DJ_CONV_STATS_MAY_SPLIT).
         # Same box, deconv B=32: limit 256 -> 25.08 ms, 512..700 -> 24.94, 1500 -> 25.12.
         tile_limit = int(os.environ.get("DJ_SPLIT_SMALL_BN_TILES", "512"))
         few_tiles = (-(-(b * desc.out_h * desc.out_w) // 64)) * (-(-self.filters // 64)) < tile_limit
         split_instead = bn_consumer and few_tiles and os.environ.get("DJ_SPLIT_SMALL_BN", "1") != "0"
-        if bn_consumer and not split_instead:
-            if os.environ.get("DJ_FUSE_BNFIN", "0") == "1":
+        if bn_consumer:
+            if os.environ.get("DJ_FUSE_BNFIN", "0") == "1" and not split_instead:
                 # opt-in: the conv's last workgroup turns the column sums into the BatchNormalization coefficients itself
                 # (fp64 accumulators + a ticket, both left zero by that workgroup).  Saves the finalize launch but every
                 # workgroup pays a ticket round trip: 0.6 % SLOWER on the SSD300 step, hence off
@@ -421,11 +421,10 @@ class Conv2D(Layer):
             else:
                 nrows = Kn.conv2d_stats_rows(desc)
                 stats = plan.empty(nrows, 2, self.filters)
-        # a split-K forward (the small-M head convs) accumulates with atomics into a cleared y: take y from the arena
-        # that one memset clears per step rather than clearing it inside the launch
-        y_zeroed = (stats is None and fused_bn is None and (engine.tuned_splits(0, desc) or 1) > 1
-                    and os.environ.get("DJ_ZERO_ARENA", "1") != "0")
-        y = (plan.zeroed_each_step if y_zeroed else plan.empty)(b, desc.out_h, desc.out_w, self.filters)
+        # a split-K forward (the small-M layers) leaves its partial tiles in the plan's workspace and a fixed-order
+        # reduction writes y (and takes the statistics of a `split_instead` launch): bit-reproducible, no cleared y
+        y = plan.empty(b, desc.out_h, desc.out_w, self.filters)
+        ws = plan.conv_workspace(desc, stats_may_split=split_instead)
         xbuf = x.buf
         pend = getattr(x, "pending_add", None)
         if pend is not None:
@@ -438,14 +437,16 @@ class Conv2D(Layer):
                                                                  xbuf))
             else:
                 plan.emit_conv(4 if stats is not None else 0, desc,
-                               lambda: Kn.conv2d_fwd_addrelu(desc, zb, wgt, bias, y, zs, zt, rb, rs, rt, xbuf, relu, stats))
+                               lambda: Kn.conv2d_fwd_addrelu(desc, zb, wgt, bias, y, zs, zt, rb, rs, rt, xbuf, relu, stats,
+                                                             workspace=ws.buf))
             x.pending_add = None
             plan.mark_ready(x)     # the sum exists from here on: its other readers may run beside the main chain
         elif fused_bn is not None:
             plan.emit_conv(4, desc, lambda: Kn.conv2d_fwd_bn(desc, xbuf, wgt, bias, y, bn_arg, pro[0], pro[1], pro[2]))
         else:
-            plan.emit_conv(4 if stats is not None else 0, desc,
-                           lambda: Kn.conv2d_fwd(desc, xbuf, wgt, bias, y, pro[0], pro[1], pro[2], relu, stats, y_zeroed))
+            plan.emit_conv(4 if (stats is not None and not split_instead) else 0, desc,
+                           lambda: Kn.conv2d_fwd(desc, xbuf, wgt, bias, y, pro[0], pro[1], pro[2], relu, stats,
+                                                 workspace=ws.buf, stats_may_split=split_instead))
         out = Value(y, needs_grad=True, name=self.name)
         if stats is not None:
             out.conv_stats = (stats, stats.shape[0], bias)
@@ -526,7 +527,7 @@ class Conv2DTranspose(Layer):
         assert (desc.out_h, desc.out_w) == (h, w)
         y = plan.empty(b, oh, ow, self.filters)
         wgt, bias = self.kernel.param, (self.bias.param if self.bias is not None else None)
-        plan.emit_conv(1, desc, lambda: Kn.conv2d_dgrad(desc, xbuf, wgt, y, bias, False))
+        plan.emit_conv(1, desc, lambda: Kn.conv2d_dgrad(desc, xbuf, wgt, y, bias, False, no_split=True))
         out = Value(y, needs_grad=True, name=self.name)
 
         def build_backward():
@@ -586,7 +587,8 @@ class Dense(Layer):
         wgt = self.kernel.param.view(1, 1, cin, self.units)
         bias = self.bias.param if self.bias is not None else None
         relu = self.activation == "relu"
-        plan.emit(lambda: Kn.conv2d_fwd(desc, x4, wgt, bias, z, relu=relu))
+        ws = plan.conv_workspace(desc)
+        plan.emit(lambda: Kn.conv2d_fwd(desc, x4, wgt, bias, z, relu=relu, workspace=ws.buf))
         zv = Value(z.view(b, self.units), needs_grad=True, name=self.name)
         out = zv
         if self.activation == "softmax":

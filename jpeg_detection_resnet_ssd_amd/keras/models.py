@@ -305,6 +305,7 @@ class Model(object):
                              verbose=os.environ.get("DJ_AUTOTUNE_VERBOSE", "0") == "1",
                              measure=os.environ.get("DJ_AUTOTUNE", "1") != "table"):
                 state.copy_(saved)
+            plan.finalize_workspaces()
             if os.environ.get("DJ_TUNE_SAVE"):
                 from ..engine import save_tune_db
                 save_tune_db(os.environ["DJ_TUNE_SAVE"])

@@ -80,14 +80,26 @@ def conv2d_stats_rows(desc):
 
 
 def conv2d_fwd(desc, x, w, bias, y, pro_scale=None, pro_shift=None, pro_relu=False, relu=False, stats=None,
-               y_zeroed=False):
-    """`y_zeroed`: y is all zeros on entry (a split-K launch then skips its own memset)."""
+               y_zeroed=False, workspace=None, stats_may_split=False):
+    """`y_zeroed`: y is all zeros on entry (a split-K launch then skips its own memset).
+    `workspace` (float tensor): split-K launches go through slabs + a fixed-order reduction (bit-reproducible) when it is
+    large enough (conv2d_fwd_workspace_floats); `stats_may_split`: a launch with `stats` may then be split too."""
     d = _desc_for(desc, x, y)
     assert w.is_contiguous() and tuple(w.shape) == (d.kernel_h, d.kernel_w, d.in_c, d.out_c)
+    if workspace is not None:
+        flags = int(bool(relu)) | (2 if y_zeroed else 0) | (4 if stats_may_split else 0)
+        check(_lib.load().dj_conv2d_nhwc_fwd_ws(d, ptr(x), ptr(w), ptr(bias), ptr(y), ptr(pro_scale), ptr(pro_shift),
+                                                int(pro_relu), flags, ptr(stats), ptr(workspace), workspace.numel(),
+                                                _stream()), "dj_conv2d_nhwc_fwd_ws")
+        return y
     check(_lib.load().dj_conv2d_nhwc_fwd(d, ptr(x), ptr(w), ptr(bias), ptr(y), ptr(pro_scale), ptr(pro_shift),
                                          int(pro_relu), int(bool(relu)) | (2 if y_zeroed else 0), ptr(stats), _stream()),
           "dj_conv2d_nhwc_fwd")
     return y
+
+
+def conv2d_fwd_workspace_floats(desc, stats_may_split=False):
+    return check(_lib.load().dj_conv2d_fwd_workspace_floats(desc, int(stats_may_split)), "dj_conv2d_fwd_workspace_floats")
 
 
 def conv2d_fwd_addrelu_supported(desc):
@@ -95,11 +107,19 @@ def conv2d_fwd_addrelu_supported(desc):
 
 
 def conv2d_fwd_addrelu(desc, x, w, bias, y, pro_scale, pro_shift, res, res_scale=None, res_shift=None, sum_out=None,
-                       relu=False, stats=None):
-    """1x1 stride-1 conv of relu(x*pro_scale+pro_shift + res*res_scale+res_shift); `sum_out` receives that input."""
+                       relu=False, stats=None, workspace=None):
+    """1x1 stride-1 conv of relu(x*pro_scale+pro_shift + res*res_scale+res_shift); `sum_out` receives that input.
+    `workspace`: as for conv2d_fwd."""
     d = _desc_for(desc, x, y)
     assert w.is_contiguous() and tuple(w.shape) == (d.kernel_h, d.kernel_w, d.in_c, d.out_c)
     assert tuple(res.shape) == tuple(x.shape) and (sum_out is None or tuple(sum_out.shape) == tuple(x.shape))
+    if workspace is not None:
+        check(_lib.load().dj_conv2d_nhwc_fwd_addrelu_ws(d, ptr(x), ptr(w), ptr(bias), ptr(y), ptr(pro_scale), ptr(pro_shift),
+                                                        ptr(res), _pixel_ld(res), ptr(res_scale), ptr(res_shift),
+                                                        ptr(sum_out), _pixel_ld(sum_out) if sum_out is not None else 0,
+                                                        int(relu), ptr(stats), ptr(workspace), workspace.numel(),
+                                                        _stream()), "dj_conv2d_nhwc_fwd_addrelu_ws")
+        return y
     check(_lib.load().dj_conv2d_nhwc_fwd_addrelu(d, ptr(x), ptr(w), ptr(bias), ptr(y), ptr(pro_scale), ptr(pro_shift),
                                                  ptr(res), _pixel_ld(res), ptr(res_scale), ptr(res_shift), ptr(sum_out),
                                                  _pixel_ld(sum_out) if sum_out is not None else 0, int(relu), ptr(stats),
@@ -132,10 +152,12 @@ def conv2d_fwd_bn(desc, x, w, bias, y, bn, pro_scale=None, pro_shift=None, pro_r
     return y
 
 
-def conv2d_dgrad(desc, dy, w, dx, bias=None, beta=False):
+def conv2d_dgrad(desc, dy, w, dx, bias=None, beta=False, no_split=False):
+    """`no_split`: one K range per tile (no fp32 atomics): for the forward use as Conv2DTranspose."""
     d = _desc_for(desc, dx, dy)
     assert w.is_contiguous() and tuple(w.shape) == (d.kernel_h, d.kernel_w, d.in_c, d.out_c)
-    check(_lib.load().dj_conv2d_nhwc_dgrad(d, ptr(dy), ptr(w), ptr(bias), ptr(dx), int(beta), _stream()),
+    check(_lib.load().dj_conv2d_nhwc_dgrad(d, ptr(dy), ptr(w), ptr(bias), ptr(dx), int(bool(beta)) | (2 if no_split else 0),
+                                           _stream()),
           "dj_conv2d_nhwc_dgrad")
     return dx
 

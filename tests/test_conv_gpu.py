@@ -218,6 +218,76 @@ def test_every_tile_variant(case, cuda):
         _lib.check(lib.dj_conv2d_tune_set(direction, desc, -1, 1), "tune_set")
 
 
+SLAB_CASES = [
+    (3, 10, 10, 256, 96, 3, 1, "same", 1),      # 300 rows (partial row tile and partial 64-row statistics group), N = 96
+    (2, 5, 5, 512, 126, 1, 1, "valid", 1),      # N = 126: scalar reduction kernel, generic GEMM
+    (4, 3, 3, 128, 160, 3, 1, "same", 1),       # 36 rows, 1.25 column tiles
+]
+
+
+@pytest.mark.parametrize("case", SLAB_CASES)
+def test_split_forward_through_slabs_is_exact_and_reproducible(case, cuda):
+    """dj_conv2d_nhwc_fwd_ws: a split-K forward launch stores its partial tiles to the caller's workspace and a second
+    kernel adds them in a fixed order (+ bias, ReLU, BatchNormalization statistics).  Every tile variant, splits 1 / 2 /
+    5: result against the fp64 oracle, statistics against the result, and two launches bit-identical (the path without
+    workspace accumulates with atomics and is not).  Too small a workspace: atomics again, or -- when the statistics
+    must come from the reduction -- an unsplit launch; still correct."""
+    from jpeg_detection_resnet_ssd_amd import _lib
+    from jpeg_detection_resnet_ssd_amd import kernels as K
+    lib = _lib.load()
+    b, h, w, ci, co, kk, ss, pad, dd = _geometry(case)
+    g = torch.Generator().manual_seed(91)
+    x = torch.randn(b, h, w, ci, generator=g)
+    wt = torch.randn(kk[0], kk[1], ci, co, generator=g) * (2.0 / (kk[0] * kk[1] * ci)) ** 0.5
+    bias = torch.randn(co, generator=g)
+    sc, sh = torch.rand(ci, generator=g) + 0.5, torch.randn(ci, generator=g)
+    xa = torch.relu(x * sc + sh).double()
+    y_lin = _oracle_conv(xa, wt.double(), bias.double(), case)
+    y_nobias = (y_lin - bias.double()).reshape(-1, co)
+    desc = K.make_conv_desc(b, h, w, ci, co, kk, ss, pad, dd)
+    xd, wd, bd, scd, shd = (t.to(cuda) for t in (x, wt, bias, sc, sh))
+    rows = K.conv2d_stats_rows(desc)
+    try:
+        for cfg in range(lib.dj_conv2d_tune_configs()):
+            for splits in (1, 2, 5):
+                _lib.check(lib.dj_conv2d_tune_set(0, desc, cfg, splits), "tune_set")
+                need = K.conv2d_fwd_workspace_floats(desc, True)
+                tag = "cfg %d splits %d" % (cfg, splits)
+                assert (need > 0) == (splits > 1) and need % (y_nobias.numel()) == 0, tag
+                ws = torch.full((max(need, 4),), float("nan"), device=cuda)
+                for relu in (False, True):
+                    yr = torch.relu(y_lin) if relu else y_lin
+                    outs = []
+                    for _ in range(2):
+                        y = torch.full(y_lin.shape, float("nan"), device=cuda)
+                        stats = torch.full((rows, 2, co), float("nan"), device=cuda)
+                        K.conv2d_fwd(desc, xd, wd, bd, y, scd, shd, True, relu, stats, workspace=ws, stats_may_split=True)
+                        outs.append((y, stats))
+                    torch.cuda.synchronize()
+                    (y, stats), (y2, stats2) = outs
+                    assert torch.equal(y, y2) and torch.equal(stats, stats2), tag
+                    assert (y.cpu().double() - yr).abs().max() <= _tol(yr), tag
+                    s = stats.cpu().double()
+                    assert (s[:, 0].sum(0) - y_nobias.sum(0)).abs().max() <= 1e-3 * float(y_nobias.sum(0).abs().max()) + 1e-3, tag
+                    assert (s[:, 1].sum(0) - (y_nobias ** 2).sum(0)).abs().max() <= 1e-3 * float((y_nobias ** 2).sum(0).max()), tag
+                # without statistics, and with a workspace that is too small (atomic fallback / unsplit launch)
+                y = torch.full(y_lin.shape, float("nan"), device=cuda)
+                K.conv2d_fwd(desc, xd, wd, bd, y, scd, shd, True, False, None, workspace=ws)
+                small = torch.empty(8, device=cuda)
+                y3 = torch.full(y_lin.shape, float("nan"), device=cuda)
+                K.conv2d_fwd(desc, xd, wd, bd, y3, scd, shd, True, False, None, workspace=small)
+                y4 = torch.full(y_lin.shape, float("nan"), device=cuda)
+                stats4 = torch.full((rows, 2, co), float("nan"), device=cuda)
+                K.conv2d_fwd(desc, xd, wd, bd, y4, scd, shd, True, False, stats4, workspace=small, stats_may_split=True)
+                torch.cuda.synchronize()
+                for t in (y, y3, y4):
+                    assert (t.cpu().double() - y_lin).abs().max() <= _tol(y_lin), tag
+                assert (stats4.cpu().double()[:, 0].sum(0) - y_nobias.sum(0)).abs().max() <= \
+                    1e-3 * float(y_nobias.sum(0).abs().max()) + 1e-3, tag
+    finally:
+        _lib.check(lib.dj_conv2d_tune_set(0, desc, -1, 1), "tune_set")
+
+
 @pytest.mark.parametrize("geom", [(3, 19, 19, 256, 64), (2, 38, 38, 64, 256), (2, 10, 10, 512, 128), (1, 5, 5, 96, 32)])
 @pytest.mark.parametrize("res_affine", [False, True])
 def test_fwd_with_residual_add_prologue(geom, res_affine, cuda):

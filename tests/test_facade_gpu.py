@@ -78,13 +78,12 @@ def test_fit_generator_with_the_trainers_callbacks(cuda, tmp_path):
     assert n == len(fresh.weight_specs) == len(saved)
     probe, _ = build(ARCHI, seed=8)
     probe.set_weights_dict(saved, strict=True)
-    # same weights, two models: the boxes of the 38x38 source sit upstream of every split-K convolution and are
-    # bit-identical; downstream of fc6 (K = 18432 split over workgroups, fp32 atomics in arrival order) two evaluations
-    # of the SAME model differ in the last bits too -- measured 1e-4 of the largest value after conv6..conv9
+    # same weights, two models: bit-identical predictions.  (The forward pass has no arrival-order arithmetic: split-K
+    # launches -- fc6 with K = 18432, the small maps behind it -- go through slabs and a fixed-order reduction,
+    # dj_conv2d_nhwc_fwd_ws; until round 2 they used fp32 atomics and only the 38x38 source was reproducible.)
     a, b = fresh.predict(x, batch_size=BATCH), probe.predict(x, batch_size=BATCH)
-    n38 = 38 * 38 * 4
-    np.testing.assert_array_equal(a[:, :n38], b[:, :n38])
-    assert np.abs(a - b).max() <= 1e-3 * np.abs(a).max()
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(a, fresh.predict(x, batch_size=BATCH))
 
     # by_name with a SUBSET of the names plus names the model does not have: Keras loads what matches, silently skips
     # the rest; by_name=False insists on every weight
@@ -204,3 +203,25 @@ def test_entry_script_restart(cuda, tmp_path):
     # CSVLogger(append=True): the resumed run continues the same log at epoch index `epoch_in_name`, runs one epoch
     assert [r_[0] for r_ in rows[1:]] == ["0", "1", str(epoch_in_name)]
     assert ("Epoch %d/%d" % (epoch_in_name + 1, epoch_in_name + 1)) in r.stdout
+
+
+@pytest.mark.parametrize("archi", ["deconv", "ssd_custom", "up_sampling"])
+def test_training_forward_pass_is_bit_reproducible(archi, cuda):
+    """No arrival-order arithmetic in the forward pass, training mode included: split-K launches reduce their slabs in a
+    fixed order (and take the BatchNormalization statistics there), Conv2DTranspose runs unsplit, statistics are two-stage
+    sums, the predictor heads on the side stream are ordered by events.  Three evaluations of the same batch: identical
+    predictions, bit for bit, and identical batch statistics in every BatchNormalization."""
+    from test_ssd_gpu import build, make_batch, perturb_weights
+    model, sizes = build(archi)
+    perturb_weights(model)
+    x, y = make_batch(archi, sizes, 4, seed=17)
+    plan = model._plan(4, True, True)
+    model._upload(plan, x, y)
+    runs = []
+    for _ in range(3):
+        plan.run_forward()
+        torch.cuda.synchronize()
+        runs.append([plan.outputs[0].buf.clone(), plan.loss_out.clone()])
+    for r in runs[1:]:
+        assert torch.equal(r[0], runs[0][0])
+        assert torch.equal(r[1], runs[0][1])

@@ -84,14 +84,14 @@ class Replay(object):
 
     def fwd(self, orig):
         def run(desc, x, w, bias, y, pro_scale=None, pro_shift=None, pro_relu=False, relu=False, stats=None,
-                y_zeroed=False):
+                y_zeroed=False, **kw):     # kw: workspace / stats_may_split (split-K through slabs)
             key = ("fwd", self._geom(desc), pro_scale is not None, bool(pro_relu), bool(relu), stats is not None,
-                   bool(y_zeroed), bias is not None)
+                   bool(y_zeroed), bias is not None, bool(kw.get("stats_may_split")))
             if key in self.seen:
-                return orig(desc, x, w, bias, y, pro_scale, pro_shift, pro_relu, relu, stats, y_zeroed)
+                return orig(desc, x, w, bias, y, pro_scale, pro_shift, pro_relu, relu, stats, y_zeroed, **kw)
             self.seen.add(key)
             before = y.clone() if y_zeroed else None
-            orig(desc, x, w, bias, y, pro_scale, pro_shift, pro_relu, relu, stats, y_zeroed)
+            orig(desc, x, w, bias, y, pro_scale, pro_shift, pro_relu, relu, stats, y_zeroed, **kw)
             torch.cuda.synchronize()
             t0 = time.time()
             a = _f64(x)
@@ -119,13 +119,13 @@ class Replay(object):
 
     def fwd_addrelu(self, orig):
         def run(desc, x, w, bias, y, pro_scale, pro_shift, res, res_scale=None, res_shift=None, sum_out=None,
-                relu=False, stats=None):
+                relu=False, stats=None, **kw):
             key = ("fwd_addrelu", self._geom(desc), res_scale is not None, sum_out is not None, bool(relu),
                    stats is not None)
             if key in self.seen:
-                return orig(desc, x, w, bias, y, pro_scale, pro_shift, res, res_scale, res_shift, sum_out, relu, stats)
+                return orig(desc, x, w, bias, y, pro_scale, pro_shift, res, res_scale, res_shift, sum_out, relu, stats, **kw)
             self.seen.add(key)
-            orig(desc, x, w, bias, y, pro_scale, pro_shift, res, res_scale, res_shift, sum_out, relu, stats)
+            orig(desc, x, w, bias, y, pro_scale, pro_shift, res, res_scale, res_shift, sum_out, relu, stats, **kw)
             torch.cuda.synchronize()
             t0 = time.time()
             r = _f64(res)
@@ -150,13 +150,13 @@ class Replay(object):
         return run
 
     def dgrad(self, orig):
-        def run(desc, dy, w, dx, bias=None, beta=False):
+        def run(desc, dy, w, dx, bias=None, beta=False, **kw):
             key = ("dgrad", self._geom(desc), bias is not None, bool(beta))
             if key in self.seen:
-                return orig(desc, dy, w, dx, bias, beta)
+                return orig(desc, dy, w, dx, bias, beta, **kw)
             self.seen.add(key)
             before = dx.clone() if beta else None
-            orig(desc, dy, w, dx, bias, beta)
+            orig(desc, dy, w, dx, bias, beta, **kw)
             torch.cuda.synchronize()
             t0 = time.time()
             x0 = torch.zeros(tuple(dx.shape), dtype=torch.float64, requires_grad=True)
