@@ -171,6 +171,13 @@ static int extent_bytes(long pixels, long ld, long c) {
   return (b > 0 && b < 0x7FFFFFF0L) ? (int)b : 0;
 }
 
+// reciprocals of the row grid (p.rowH, p.rowW must be set): the kernels decompose a GEMM row into (image, h, w) with a
+// float multiply and a one-step correction instead of integer divisions
+static void set_row_recip(DjIgemmParams& p) {
+  p.inv_rowHW = 1.0f / (float)(p.rowH * p.rowW);
+  p.inv_rowW = 1.0f / (float)p.rowW;
+}
+
 static void fill_geom(DjIgemmParams& p, const dj_conv2d_desc* d) {
   p.KH = d->kernel_h;
   p.KW = d->kernel_w;
@@ -180,6 +187,7 @@ static void fill_geom(DjIgemmParams& p, const dj_conv2d_desc* d) {
   p.dW = d->dilation_w;
   p.pT = d->pad_top;
   p.pL = d->pad_left;
+  set_row_recip(p);
 }
 
 extern "C" int dj_conv2d_fwd_stats_rows(const dj_conv2d_desc* d) {
@@ -562,6 +570,7 @@ extern "C" int dj_conv2d_nhwc_dgrad(const dj_conv2d_desc* d, const float* dy, co
     p.KH = p.KW = 1;
     p.sH = p.sW = p.dH = p.dW = 1;
     p.pT = p.pL = 0;
+    set_row_recip(p);
     p.cmap = 1;
     p.cgH = d->out_h;
     p.cgW = d->out_w;
@@ -640,8 +649,6 @@ extern "C" int dj_conv2d_nhwc_wgrad(const dj_conv2d_desc* d, const float* x, con
   p.vecB = (d->out_c % 4 == 0) && (d->ld_y % 4 == 0) && aligned16(dy);
   p.a_bytes = extent_bytes((long)d->batch * d->in_h * d->in_w, d->ld_x, d->in_c);
   p.b_bytes = extent_bytes((long)d->batch * d->out_h * d->out_w, d->ld_y, d->out_c);
-  p.inv_rowHW = 1.0f / (float)(d->out_h * d->out_w);
-  p.inv_rowW = 1.0f / (float)d->out_w;
   // tile by the (taps*Cin) x Cout extent only -- the pixel reduction is split over blockIdx.y to fill the chip
   int splits = 1;
   int cfg;

@@ -150,6 +150,7 @@ static int fast_mode(const DjIgemmParams& p) {
   if (!g_dj_allow_fast.load(std::memory_order_relaxed) || !p.vecA || !p.vecB) return 0;
   if (p.a_bytes <= 0 || p.b_bytes <= 0) return 0;  // operand >= 2 GiB (extent overflowed int)
   if (AM != 2 && p.srcC % 32 != 0) return 0;
+  if (AM != 2 && p.M >= (1 << 22)) return 0;   // dj_row_decompose: float-reciprocal row decomposition
   if (AM == 1 && (p.sH != 1 || p.sW != 1)) return 0;
   if (AM == 2 && (p.srcC % 4 != 0 || p.K >= (1 << 24))) return 0;
   if (BMD == 0 && (p.N % 4 != 0 || p.ldb % 4 != 0)) return 0;
@@ -161,27 +162,58 @@ static int fast_mode(const DjIgemmParams& p) {
 // reduced-precision MFMA variants exist for the two-stage 128x128 / 128x64 / 64x64 tiles of the fast kernel
 static inline int dj_fast_mode_fwd(const DjIgemmParams& p) { return fast_mode<0, 0>(p); }
 
+// BK: K-step depth of the 16-bit-tile kernel (64: forward / input gradient), PF: K-steps of register prefetch -- see
+// dj_igemm_h16.h
+template <int BM, int BN, int AM, int BMD, int PREC, int BK, int PF>
+static int launch_h16(const DjIgemmParams& p, int splits, hipStream_t s, int fast) {
+  using H = DjH16Cfg<BM, BN, AM, BMD, BK>;
+  if (fast == 3) {
+    if constexpr (AM == 0 && BMD == 0) {
+      static bool hdone3 = false;
+      return launch_kernel(dj_igemm_h16_kernel<BM, BN, AM, BMD, 3, PREC, BK, PF>, H::SMEM_BYTES, BM, BN, p, splits, s,
+                           &hdone3);
+    } else {
+      dj_set_error("residual-add prologue outside the forward GEMM");
+      return DJ_ERR_ARG;
+    }
+  }
+  static bool hdone[2] = {false, false};
+  if (fast == 1)
+    return launch_kernel(dj_igemm_h16_kernel<BM, BN, AM, BMD, 0, PREC, BK, PF>, H::SMEM_BYTES, BM, BN, p, splits, s,
+                         &hdone[0]);
+  if constexpr (AM != 1) {  // the input-gradient GEMM has no prologue
+    return launch_kernel(dj_igemm_h16_kernel<BM, BN, AM, BMD, 1, PREC, BK, PF>, H::SMEM_BYTES, BM, BN, p, splits, s,
+                         &hdone[1]);
+  } else {
+    dj_set_error("prologue on the input-gradient GEMM");
+    return DJ_ERR_ARG;
+  }
+}
+
+template <int BM, int BN, int AM, int BMD, int PREC, int PF>
+static int launch_h16_depth(const DjIgemmParams& p, int splits, hipStream_t s, int fast, bool deep) {
+  if constexpr (AM != 2) {
+    // 64-deep K-steps where a step stays inside one filter tap and every K chunk is whole (DJ_H16_BK32=1: never)
+    static const bool bk32 = getenv("DJ_H16_BK32") != nullptr;
+    if (deep && !bk32 && p.srcC % 64 == 0 && p.kchunk % 64 == 0)
+      return launch_h16<BM, BN, AM, BMD, PREC, 64, PF>(p, splits, s, fast);
+  }
+  return launch_h16<BM, BN, AM, BMD, PREC, 32, PF>(p, splits, s, fast);
+}
+
 template <int BM, int BN, int AM, int BMD, int PREC>
-static int launch_lowp(const DjIgemmParams& p, int splits, hipStream_t s, int fast) {
+static int launch_lowp(const DjIgemmParams& p, int splits, hipStream_t s, int fast, bool deep, bool pf2) {
   using Cfg = DjIgemmCfg<BM, BN, 2, 2, AM, BMD>;
   static bool done[2] = {false, false};
   // 16-bit tiles in LDS + 16-deep MFMA (dj_igemm_h16.h); DJ_LOWP_LDS32=1 keeps the older path (fp32 tiles, fragments
   // rounded at read time, 8-deep MFMA) for A/B runs
   static const bool lds32 = getenv("DJ_LOWP_LDS32") != nullptr;
-  if (fast == 3 && !lds32) {
-    if constexpr (AM == 0 && BMD == 0) {
-      using H = DjH16Cfg<BM, BN, AM, BMD>;
-      static bool hdone3 = false;
-      return launch_kernel(dj_igemm_h16_kernel<BM, BN, AM, BMD, 3, PREC>, H::SMEM_BYTES, BM, BN, p, splits, s, &hdone3);
+  if (!lds32 && (fast == 1 || fast == 3 || (fast == 2 && AM != 1))) {
+    if constexpr (BM * BN < 128 * 128) {   // the 128x128 tile has no registers to spare for a second prefetch set
+      static const bool pf1 = getenv("DJ_H16_PF1") != nullptr;
+      if (pf2 && !pf1) return launch_h16_depth<BM, BN, AM, BMD, PREC, 2>(p, splits, s, fast, deep);
     }
-  }
-  if ((fast == 1 || fast == 2) && !lds32) {
-    using H = DjH16Cfg<BM, BN, AM, BMD>;
-    static bool hdone[2] = {false, false};
-    if (fast == 1)
-      return launch_kernel(dj_igemm_h16_kernel<BM, BN, AM, BMD, 0, PREC>, H::SMEM_BYTES, BM, BN, p, splits, s, &hdone[0]);
-    if constexpr (AM != 1)   // the input-gradient GEMM has no prologue
-      return launch_kernel(dj_igemm_h16_kernel<BM, BN, AM, BMD, 1, PREC>, H::SMEM_BYTES, BM, BN, p, splits, s, &hdone[1]);
+    return launch_h16_depth<BM, BN, AM, BMD, PREC, 1>(p, splits, s, fast, deep);
   }
   if (fast == 1)
     return launch_kernel(dj_igemm_fast_kernel<BM, BN, 2, 2, AM, BMD, 0, 2, PREC>, Cfg::SMEM_BYTES, BM, BN, p, splits, s,
@@ -200,12 +232,21 @@ static int launch_lowp(const DjIgemmParams& p, int splits, hipStream_t s, int fa
                        &done[1]);
 }
 
+// Reduced-precision variants behind the fourteen configuration indices of the tuner (the schedule variants of the fp32
+// kernel do not exist here; their indices select K-step depth and prefetch depth of the 16-bit-tile kernel instead):
+//   tile 128x128: 0, 4 = 32-deep; 9 = 64-deep (one prefetch set)
+//   tile 128x64:  1 = 32-deep; 5 = 32-deep, two prefetch sets; 10 = 64-deep; 8, 13 = 64-deep, two prefetch sets
+//   tile 64x64:   2 = 32-deep; 3, 6 = 32-deep, two prefetch sets; 11 = 64-deep; 7, 12 = 64-deep, two prefetch sets
+// (the weight gradient, whose reduction runs over pixels, has 32-deep K-steps only)
 template <int AM, int BMD, int PREC>
 static int launch_lowp_cfg(int cfg, const DjIgemmParams& p, int splits, hipStream_t s, int fast) {
   const int bm = kCfgs[cfg].bm, bn = kCfgs[cfg].bn;
-  if (bm == 128 && bn == 128) return launch_lowp<128, 128, AM, BMD, PREC>(p, splits, s, fast);
-  if (bm == 128 && bn == 64) return launch_lowp<128, 64, AM, BMD, PREC>(p, splits, s, fast);
-  return launch_lowp<64, 64, AM, BMD, PREC>(p, splits, s, fast);   // 64x64 and 128x32 requests
+  const bool deep = cfg >= CFG_64x64_S1P;
+  const bool pf2 = cfg == CFG_128x32 || cfg == CFG_128x64_S1 || cfg == CFG_64x64_S1 || cfg == CFG_64x64_S1P ||
+                   cfg == CFG_128x64_S1P || cfg == CFG_64x64_PK2 || cfg == CFG_128x64_PK2;
+  if (bm == 128 && bn == 128) return launch_lowp<128, 128, AM, BMD, PREC>(p, splits, s, fast, deep, pf2);
+  if (bm == 128 && bn == 64) return launch_lowp<128, 64, AM, BMD, PREC>(p, splits, s, fast, deep, pf2);
+  return launch_lowp<64, 64, AM, BMD, PREC>(p, splits, s, fast, deep, pf2);   // 64x64 and 128x32 requests
 }
 
 template <int AM, int BMD>

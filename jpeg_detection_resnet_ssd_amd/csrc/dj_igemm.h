@@ -96,6 +96,22 @@ struct DjIgemmCfg {
 
 __device__ __forceinline__ f32x4 dj_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+// GEMM row m -> (image, h, w) on the rowH x rowW pixel grid.  gfx950 has no integer division: `m / d` expands to ~25
+// vector instructions, four of them quarter-rate multiplies, and on the fp32 matrix pipe every vector instruction of
+// a tile's prologue is paid in full (tools/micro/mfma_valu.hip).  Below 2^22 (the fast kernels' launcher checks M) the
+// float reciprocal lands within one of the quotient; a compare on the remainder corrects it (full-rate instructions only).
+__device__ __forceinline__ void dj_row_decompose(const DjIgemmParams& p, int m, int& img, int& h, int& w) {
+  const int hw = p.rowH * p.rowW;
+  img = (int)((float)m * p.inv_rowHW);
+  int rem = m - __mul24(img, hw);
+  img += (rem < 0) ? -1 : ((rem >= hw) ? 1 : 0);
+  rem += (rem < 0) ? hw : ((rem >= hw) ? -hw : 0);
+  h = (int)((float)rem * p.inv_rowW);
+  w = rem - __mul24(h, p.rowW);
+  h += (w < 0) ? -1 : ((w >= p.rowW) ? 1 : 0);
+  w += (w < 0) ? p.rowW : ((w >= p.rowW) ? -p.rowW : 0);
+}
+
 // Scalar fall-back of one gathered A element for A-modes 0/1 (used when 16-byte
 // loads are not legal, e.g. Cin = 3).
 template <int AM>

@@ -143,10 +143,8 @@ __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmPa
       int m = m0 + ar0 + 32 * j;
       row_valid |= (m < p.M) ? (1u << j) : 0u;
       if (m < p.M) {
-        int img = m / (p.rowH * p.rowW);
-        int rem = m - img * (p.rowH * p.rowW);
-        int h = rem / p.rowW;
-        int w = rem - h * p.rowW;
+        int img, h, w;
+        dj_row_decompose(p, m, img, h, w);
         int rh = (AM == 0) ? h * p.sH - p.pT : h + p.pT;
         int rw = (AM == 0) ? w * p.sW - p.pL : w + p.pL;
         a_rh[j] = rh;

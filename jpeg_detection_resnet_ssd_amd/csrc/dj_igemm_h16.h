@@ -8,18 +8,24 @@
 // reads, 8-deep MFMA): half the LDS bytes, each element converted once instead of once per reading wave, and half the
 // MFMA instructions per K-step.
 //
-// LDS images (16-bit elements), one K-step = 32 k:
-//   * k-contiguous operand (A of forward / input gradient, B of the input gradient): [rows][32 k], pitch 40 elements
-//     (80 B: 16-byte aligned rows, conflict-free for the 16-lane groups of ds_read_b128).  Lane (row r, half h) reads
+// LDS images (16-bit elements), one K-step = BK k (32, or 64 for forward / input gradient: see BK below):
+//   * k-contiguous operand (A of forward / input gradient, B of the input gradient): [rows][BK k], pitch BK + 8 elements
+//     (80 / 144 B: 16-byte aligned rows, conflict-free for the 16-lane groups of ds_read_b128).  Lane (row r, half h) reads
 //     k = 16 s + 8 h .. + 7 of MFMA step s with one ds_read_b128: exactly its operand of v_mfma_*_32x32x16.
 //   * the operand that is contiguous along the OTHER GEMM dimension (HWIO weights in the forward pass; both operands of the
-//     weight gradient, whose reduction runs over pixels): stored as it arrives, [32 k][cols], pitch cols + 32 elements,
+//     weight gradient, whose reduction runs over pixels): stored as it arrives, [BK k][cols], pitch cols + 32 elements,
 //     and read with ds_read_b64_tr_b16, gfx950's transposing LDS read: a 16-lane group hands in 4 row (k) addresses x
 //     16 columns and every lane receives the 4 k values of ITS column -- two of them are a lane's 8-deep operand.  The
 //     pitch puts the 4 rows x 2 column groups of a 32-lane half on 64 different banks.
 // The global-load side (buffer loads with out-of-range offsets for halo / tails, wave-uniform tap state, the
 // BatchNormalization(+ReLU) prologue in fp32 before the rounding, XCD-aware tile order, split-K) and the epilogue are
 // those of the fp32 kernel.
+//
+// BK: with 16-bit MFMAs a 32-deep K-step is 2-8 matrix instructions per wave (64-256 cycles) between two barriers, and
+// the loads of the next step have just that long to land: a workgroup's K-loop is a chain of global-load latencies
+// (19x19 3x3 256->256 forward, 64x64 tiles: 72 steps of ~0.9 us = the 68 us the launch takes).  BK = 64 halves the
+// number of links in that chain: twice the bytes in flight per thread and twice the MFMAs per barrier (forward and input
+// gradient, channel counts that are multiples of 64; the weight gradient, whose reduction runs over pixels, keeps 32).
 #pragma once
 #include "dj_igemm.h"
 #include "dj_igemm_fast.h"
@@ -30,13 +36,18 @@ typedef _Float16 dj_half8 __attribute__((ext_vector_type(8)));
 typedef __bf16 dj_bf16x8 __attribute__((ext_vector_type(8)));
 typedef short __attribute__((address_space(3))) dj_lds_short;
 
-template <int BM, int BN, int AM, int BMD>
+template <int BM, int BN, int AM, int BMD, int BK = 32>
 struct DjH16Cfg {
+  static_assert(BK == 32 || (BK == 64 && AM != 2), "64-deep K-steps: forward / input gradient only");
   static constexpr int TM = BM / 64, TN = BN / 64;   // 4 waves as 2 x 2
-  static constexpr int NA = BM / 32, NB = BN / 32;
   static constexpr bool A_KC = (AM != 2), B_KC = (BMD == 1);
-  static constexpr int PA = A_KC ? 40 : BM + 32, PB = B_KC ? 40 : BN + 32;   // pitches, in 16-bit elements
-  static constexpr int A_H = (A_KC ? BM : 32) * PA, B_H = (B_KC ? BN : 32) * PB;
+  // k-contiguous operands: a row of a K-step is KCH 16-byte chunks of four fp32; the 256 threads cover RPP rows per pass
+  static constexpr int KCH = BK / 4, RPP = 256 / KCH;
+  // the other layout ([k][cols], four columns per thread): 1024 / cols k rows per pass
+  static constexpr int NA = A_KC ? BM / RPP : BM / 32;   // 16-byte loads per thread and K-step
+  static constexpr int NB = B_KC ? BN / RPP : BK * BN / 1024;
+  static constexpr int PA = A_KC ? BK + 8 : BM + 32, PB = B_KC ? BK + 8 : BN + 32;   // pitches, in 16-bit elements
+  static constexpr int A_H = (A_KC ? BM : BK) * PA, B_H = (B_KC ? BN : BK) * PB;
   static constexpr int STAGE_H = A_H + B_H;
   static constexpr int SMEM_BYTES = 2 * STAGE_H * 2;
 };
@@ -50,11 +61,15 @@ __device__ __forceinline__ dj_short4 dj_round4(f32x4 v) {
 // PRO: 0 plain A, 1 A*scale[c]+shift[c] (+ReLU) on in-bounds elements, 3 the residual-add prologue of the forward 1x1
 // convolutions, relu(A*scale+shift + A2*scale2+shift2), whose column-tile-0 workgroups also store that sum (fp32) to
 // p.sum_out (see dj_igemm_fast.h).  PREC: 1 fp16, 2 bf16.
-template <int BM, int BN, int AM, int BMD, int PRO, int PREC>
+// PF: K-steps of register prefetch.  1: the loads of tile kt+1 are issued at the top of step kt and stored to LDS in its
+// middle.  2: two register sets -- the loads of tile kt+2 are issued at the top of step kt, tile kt+1 (issued a whole
+// step earlier) goes to LDS: a load has a full K-step longer to land (small tiles, whose steps are short; costs one
+// more set of staging registers).
+template <int BM, int BN, int AM, int BMD, int PRO, int PREC, int BK = 32, int PF = 1>
 __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p) {
-  using Cfg = DjH16Cfg<BM, BN, AM, BMD>;
+  using Cfg = DjH16Cfg<BM, BN, AM, BMD, BK>;
   constexpr int TM = Cfg::TM, TN = Cfg::TN, NA = Cfg::NA, NB = Cfg::NB;
-  constexpr int PA = Cfg::PA, PB = Cfg::PB;
+  constexpr int PA = Cfg::PA, PB = Cfg::PB, KCH = Cfg::KCH, RPP = Cfg::RPP;
   constexpr int WN = 2;
   extern __shared__ __attribute__((aligned(16))) float smem_base[];
   short* const smem = reinterpret_cast<short*>(smem_base);
@@ -76,7 +91,7 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int kbeg = blockIdx.y * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
-  const int nk = (kend - kbeg + DJ_BK - 1) / DJ_BK;
+  const int nk = (kend - kbeg + BK - 1) / BK;
 
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
@@ -88,10 +103,11 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
   const bool store_sum = (PRO == 3) && p.sum_out != nullptr && tile_n == 0;
 
   // ---------------- per-thread staging state (as in dj_igemm_fast.h) ----------------
-  const int ac = tid & 7, ar0 = tid >> 3;
+  const int ac = (AM != 2) ? tid % KCH : tid & 7, ar0 = (AM != 2) ? tid / KCH : tid >> 3;
+  constexpr int ARPP = (AM != 2) ? RPP : 32;   // A rows between a thread's loads
   constexpr int BKSTEP = 1024 / BN;
   const int bcn = tid % (BN / 4), bkr0 = tid / (BN / 4);
-  const int bc = tid & 7, br0 = tid >> 3;
+  const int bc = tid % KCH, br0 = tid / KCH;
 
   int a_off[NA], a_rh[NA], a_rw[NA];
   int r2_off[PRO == 3 ? NA : 1], y_off[PRO == 3 ? NA : 1];   // PRO 3: the same pixel in A2 / sum_out
@@ -101,12 +117,10 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
   if (AM != 2) {
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-      int m = m0 + ar0 + 32 * j;
+      int m = m0 + ar0 + ARPP * j;
       if (m < p.M) {
-        int img = m / (p.rowH * p.rowW);
-        int rem = m - img * (p.rowH * p.rowW);
-        int h = rem / p.rowW;
-        int w = rem - h * p.rowW;
+        int img, h, w;
+        dj_row_decompose(p, m, img, h, w);
         int rh = (AM == 0) ? h * p.sH - p.pT : h + p.pT;
         int rw = (AM == 0) ? w * p.sW - p.pL : w + p.pL;
         a_rh[j] = rh;
@@ -155,7 +169,7 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
   } else {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      int n = n0 + br0 + 32 * j;
+      int n = n0 + br0 + RPP * j;
       b_ok[j] = n < p.N;
       b_off[j] = (n * p.ldb + 4 * bc) * 4;
     }
@@ -169,13 +183,27 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
     t_kw = t_tap - t_kh * p.KW;
   }
 
-  f32x4 ra[NA], rb[NB];
-  unsigned a_valid = 0;
-  f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
-  f32x4 ra2[PRO == 3 ? NA : 1], psc2 = {1.f, 1.f, 1.f, 1.f}, psh2 = {0.f, 0.f, 0.f, 0.f};
-  int pro_c0 = 0;
+  // one K-step's operands between the buffer loads and the LDS stores
+  struct Regs {
+    f32x4 ra[NA], rb[NB];
+    unsigned a_valid;
+    f32x4 psc, psh;
+    f32x4 ra2[PRO == 3 ? NA : 1], psc2, psh2;
+    int pro_c0;
+  };
+  Regs r0, r1;
+  r0.a_valid = r1.a_valid = 0;
+  r0.pro_c0 = r1.pro_c0 = 0;
+  r0.psc = r1.psc = r0.psc2 = r1.psc2 = f32x4{1.f, 1.f, 1.f, 1.f};
+  r0.psh = r1.psh = r0.psh2 = r1.psh2 = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto issue_loads = [&](int kcur, bool live) {
+  auto issue_loads = [&](Regs& R, int kcur, bool live) {
+    f32x4(&ra)[NA] = R.ra;
+    f32x4(&rb)[NB] = R.rb;
+    f32x4(&ra2)[PRO == 3 ? NA : 1] = R.ra2;
+    unsigned& a_valid = R.a_valid;
+    f32x4 &psc = R.psc, &psh = R.psh, &psc2 = R.psc2, &psh2 = R.psh2;
+    int& pro_c0 = R.pro_c0;
     if (AM != 2) {
       const int dh = t_kh * p.dH, dw = t_kw * p.dW;
       const int delta = (AM == 0) ? ((dh * p.srcW + dw) * p.ldsrc + t_c0) * 4 : (-(dh * p.srcW + dw) * p.ldsrc + t_c0) * 4;
@@ -242,7 +270,7 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
       for (int j = 0; j < NB; ++j) rb[j] = dj_buf_ld4(rB, (live && b_ok[j]) ? (unsigned)b_off[j] + base : DJ_OOB);
     }
     if (AM != 2 || BMD == 1) {
-      t_c0 += DJ_BK;
+      t_c0 += BK;
       const int wrap = (t_c0 >= p.srcC) ? 1 : 0;
       t_c0 = wrap ? 0 : t_c0;
       t_tap += wrap;
@@ -254,7 +282,13 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
   };
 
   // prologue in fp32, then ONE rounding per element, 8-byte LDS stores
-  auto store_tiles = [&](short* sA, short* sB) {
+  auto store_tiles = [&](const Regs& R, short* sA, short* sB) {
+    const f32x4(&ra)[NA] = R.ra;
+    const f32x4(&rb)[NB] = R.rb;
+    const f32x4(&ra2)[PRO == 3 ? NA : 1] = R.ra2;
+    const unsigned a_valid = R.a_valid;
+    const f32x4 psc = R.psc, psh = R.psh, psc2 = R.psc2, psh2 = R.psh2;
+    const int pro_c0 = R.pro_c0;
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       f32x4 v = ra[j];
@@ -272,12 +306,12 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rY,
                                                  ok ? (int)(y_off[j] + pro_c0 * 4) : (int)DJ_OOB, 0, 0);
       }
-      short* dst = (AM != 2) ? sA + (ar0 + 32 * j) * PA + 4 * ac : sA + ar0 * PA + 4 * (ac + 8 * j);
+      short* dst = (AM != 2) ? sA + (ar0 + ARPP * j) * PA + 4 * ac : sA + ar0 * PA + 4 * (ac + 8 * j);
       *reinterpret_cast<dj_short4*>(dst) = dj_round4<PREC>(v);
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      short* dst = (BMD == 0) ? sB + (bkr0 + BKSTEP * j) * PB + 4 * bcn : sB + (br0 + 32 * j) * PB + 4 * bc;
+      short* dst = (BMD == 0) ? sB + (bkr0 + BKSTEP * j) * PB + 4 * bcn : sB + (br0 + RPP * j) * PB + 4 * bc;
       *reinterpret_cast<dj_short4*>(dst) = dj_round4<PREC>(rb[j]);
     }
   };
@@ -324,18 +358,33 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
       }
   };
 
-  // two LDS stages: tile kt+1 is loaded and stored while tile kt is multiplied
-  issue_loads(kbeg, nk > 0);
-  store_tiles(smem, smem + Cfg::A_H);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
+  // two LDS stages: tile kt+1 is stored while tile kt is multiplied
+  auto kstep = [&](Regs& load_into, const Regs& store_from, int kt, int k_load, bool live) {
     short* cur = smem + (kt & 1) * Cfg::STAGE_H;
     short* nxt = smem + ((kt + 1) & 1) * Cfg::STAGE_H;
-    issue_loads(kbeg + (kt + 1) * DJ_BK, kt + 1 < nk);
-    compute(cur, cur + Cfg::A_H, 0);
-    store_tiles(nxt, nxt + Cfg::A_H);
-    compute(cur, cur + Cfg::A_H, 1);
+    issue_loads(load_into, k_load, live);
+    if (PF == 2) __builtin_amdgcn_sched_barrier(0);   // the loads stay up here, a whole step ahead of their LDS stores
+#pragma unroll
+    for (int st = 0; st < BK / 32; ++st) compute(cur, cur + Cfg::A_H, st);
+    store_tiles(store_from, nxt, nxt + Cfg::A_H);
+#pragma unroll
+    for (int st = BK / 32; st < BK / 16; ++st) compute(cur, cur + Cfg::A_H, st);
     __syncthreads();
+  };
+  issue_loads(r0, kbeg, nk > 0);
+  if (PF == 2) issue_loads(r1, kbeg + BK, nk > 1);
+  store_tiles(r0, smem, smem + Cfg::A_H);
+  __syncthreads();
+  if (PF == 2) {
+    // step kt: tile kt+2 -> the register set tile kt just left; tile kt+1 (other set) -> LDS
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      kstep(r0, r1, kt, kbeg + (kt + 2) * BK, kt + 2 < nk);
+      kstep(r1, r0, kt + 1, kbeg + (kt + 3) * BK, kt + 3 < nk);
+    }
+    if (kt < nk) kstep(r0, r1, kt, kbeg + (kt + 2) * BK, false);
+  } else {
+    for (int kt = 0; kt < nk; ++kt) kstep(r0, r0, kt, kbeg + (kt + 1) * BK, kt + 1 < nk);
   }
   dj_igemm_epilogue<BM, BN, 2, 2>(p, acc, smem_base, tile_m, m0, n0);
 }

@@ -77,3 +77,69 @@ def test_config5_training_step_fp16_mfma(archi, floatx):
     w1 = model.get_weights_dict()
     moved = max(float(np.abs(w1[k] - w0[k]).max()) for k in w0)
     assert np.isfinite(loss) and moved > 0
+
+
+@pytest.mark.parametrize("geom", [(4, 19, 19, 256, 192, 3, 1, "same"), (3, 10, 10, 512, 256, 1, 1, "valid"),
+                                  (2, 38, 38, 64, 128, 3, 1, "same"), (5, 10, 10, 128, 320, 3, 2, "same")])
+def test_h16_every_tile_and_k_depth(geom, floatx):
+    """Every configuration index of the tuner in the reduced-precision mode = every variant of the 16-bit-tile kernel
+    (dj_igemm_h16.h: tiles 128x128 / 128x64 / 64x64, K-steps of 32 and 64, one and two register prefetch sets; the map is
+    in dj_conv_launch.h): forward with BN prologue + statistics, residual-add prologue, input gradient, with and without
+    split-K -- against the fp64 oracle at the operand-rounding tolerance, and against the first configuration at
+    fp32-accumulation-order tolerance (all variants round the same operands)."""
+    from jpeg_detection_resnet_ssd_amd import _lib
+    from jpeg_detection_resnet_ssd_amd import kernels as Kn
+    from oracle import keras_ops as ko
+    lib = _lib.load()
+    b, h, w, ci, co, k, s, pad = geom
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(b, h, w, ci, generator=g)
+    wt = torch.randn(k, k, ci, co, generator=g) * (2.0 / (k * k * ci)) ** 0.5
+    sc, sh = torch.rand(ci, generator=g) + 0.5, torch.randn(ci, generator=g) * 0.5
+    res = torch.randn(b, h, w, ci, generator=g)
+    xa = torch.relu(x * sc + sh)
+    xr, wr = xa.double().requires_grad_(True), wt.double().requires_grad_(True)
+    yr = ko.conv2d(xr, wr, None, (s, s), pad)
+    dy = torch.randn(*yr.shape, generator=g) * 1e-3
+    yr.backward(dy.double())
+    xs = torch.relu(x * sc + sh + res)
+    ys = ko.conv2d(xs.double(), wt.double(), None, (s, s), pad) if (k == 1 and s == 1) else None
+    desc = Kn.make_conv_desc(b, h, w, ci, co, (k, k), (s, s), pad, (1, 1))
+    rows = Kn.conv2d_stats_rows(desc)
+    xd, wd, dyd, scd, shd, resd = [t.cuda() for t in (x, wt, dy, sc, sh, res)]
+    floatx.set_floatx("float16")
+    first = None
+    try:
+        for cfg in range(lib.dj_conv2d_tune_configs()):
+            for splits in (1, 2):
+                tag = "cfg %d splits %d" % (cfg, splits)
+                y = torch.empty(yr.shape, device="cuda")
+                stats = torch.zeros(rows, 2, co, device="cuda")
+                _lib.check(lib.dj_conv2d_tune_set(4, desc, cfg, 1), "tune_set")
+                Kn.conv2d_fwd(desc, xd, wd, None, y, scd, shd, True, False, stats)
+                _lib.check(lib.dj_conv2d_tune_set(0, desc, cfg, splits), "tune_set")
+                y0 = torch.zeros(yr.shape, device="cuda")
+                Kn.conv2d_fwd(desc, xd, wd, None, y0, scd, shd, True, False, None, y_zeroed=True)
+                dx = torch.empty(x.shape, device="cuda")
+                _lib.check(lib.dj_conv2d_tune_set(1, desc, cfg, splits), "tune_set")
+                Kn.conv2d_dgrad(desc, dyd, wd, dx)
+                outs = [y, y0, dx]
+                if ys is not None:
+                    y3, sm = torch.empty(yr.shape, device="cuda"), torch.empty(x.shape, device="cuda")
+                    Kn.conv2d_fwd_addrelu(desc, xd, wd, None, y3, scd, shd, resd, None, None, sm)
+                    outs += [y3, sm]
+                torch.cuda.synchronize()
+                outs = [o.cpu().double() for o in outs]
+                assert rel_l2(outs[0], yr.detach()) <= 1.5e-3 and rel_l2(outs[1], yr.detach()) <= 1.5e-3, tag
+                assert rel_l2(outs[2], xr.grad) <= 8e-3, tag
+                st = stats.cpu().double()
+                assert (st[:, 0].sum(0) - outs[0].reshape(-1, co).sum(0)).abs().max() <= 1e-3 * float(yr.detach().abs().max()) * b * h * w, tag
+                if ys is not None:
+                    assert rel_l2(outs[3], ys) <= 1.5e-3 and rel_l2(outs[4], xs.double()) <= 1e-6, tag
+                if first is None:
+                    first = outs
+                for a, r in zip(outs, first):
+                    assert rel_l2(a, r) <= 2e-6, tag
+    finally:
+        for direction in (0, 4, 1):
+            _lib.check(lib.dj_conv2d_tune_set(direction, desc, -1, 1), "tune_set")

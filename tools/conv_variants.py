@@ -22,6 +22,9 @@ SHAPES = [  # name, B,H,W,Cin,Cout,k,s,pad,dil
     ("conf 38x38 64->84", 32, 38, 38, 64, 84, 3, 1, "same", 1),
 ]
 lib = _lib.load()
+if len(sys.argv) > 2:      # arithmetic mode: float16 | bfloat16 (the tile names then read: *_P / *_PK2 = 64-deep K-steps)
+    from jpeg_detection_resnet_ssd_amd.keras import backend as KB
+    KB.set_floatx(sys.argv[2])
 dev = torch.device("cuda:0")
 ncfg = lib.dj_conv2d_tune_configs()
 DIR = {"fwd": 0, "dgrad": 1, "wgrad": 2}[sys.argv[1] if len(sys.argv) > 1 else "wgrad"]
@@ -79,6 +82,6 @@ for name, b, h, w, ci, co, k, s, pad, d in SHAPES:
     print("%-26s %6.1f GFLOP | old best %-11s sp %2d %7.3f ms %6.1f TF | direct best %-7s sp %2d %7.3f ms %6.1f TF | max err %.1e"
           % (name, flop / 1e9, best_old[1], best_old[2], best_old[0], flop / best_old[0] / 1e9, best_new[1], best_new[2],
              best_new[0], flop / best_new[0] / 1e9, max(r[3] for r in rows)), flush=True)
-    for t, n, sp, err in rows[:6]:
+    for t, n, sp, err in rows[:(14 if len(sys.argv) > 2 else 6)]:
         print("      %-11s sp %2d %7.3f ms %6.1f TF err %.1e" % (n, sp, t, flop / t / 1e9, err))
     _lib.check(lib.dj_conv2d_tune_set(DIR, desc, -1, 1), "tune_set")

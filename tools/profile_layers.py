@@ -5,6 +5,9 @@ import torch
 from jpeg_detection_resnet_ssd_amd import workloads, kernels as Kn
 archi = sys.argv[1] if len(sys.argv) > 1 else "deconv"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+if len(sys.argv) > 3:      # arithmetic mode: float32 | float16 | bfloat16
+    from jpeg_detection_resnet_ssd_amd.keras import backend as KB
+    KB.set_floatx(sys.argv[3])
 model, sizes = workloads.build_ssd(archi)
 x, y = workloads.synthetic_batch(archi, sizes, B, fast=True)
 plan = model._plan(B, True, True)
