@@ -96,6 +96,27 @@ struct DjIgemmCfg {
 
 __device__ __forceinline__ f32x4 dj_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+// Workgroup -> (tile, K chunk).  Workgroups are dealt round-robin over the 8 XCDs in launch order (x fastest, then y),
+// and each XCD has its own L2.  Order the work chunk-major (all tiles of K chunk 0, then chunk 1, ...; inside a chunk the
+// column tiles of one row tile are adjacent) and give every XCD a CONTIGUOUS run of that list, taken in slot order: tiles
+// that read the same operand rows run on one L2 at about the same time.  For the weight gradient the chunk is a pixel
+// range whose x and dy rows are read by EVERY tile of the chunk: with the tiles of a chunk spread over the XCDs (what
+// `blockIdx.x % 8` gives when the split is on blockIdx.y) each L2 fetches them again -- measured on 1x1 256->1024 @38x38:
+// x fetched 4x, dy 2x (rocprofv3 FETCH_SIZE per launch, tools/pmc_layers.py), 8.6x on a 3x3 128->128.  Bijective for any grid.
+__device__ __forceinline__ void dj_tile_of_workgroup(int& tile_id, int& ky) {
+  const int gx = gridDim.x, total = gx * gridDim.y;
+  const int L = blockIdx.x + blockIdx.y * gx;
+  const int q = total >> 3, r = total & 7, xcd = L & 7, slot = L >> 3;
+  const int item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  if (gridDim.y == 1) {
+    ky = 0;
+    tile_id = item;
+  } else {
+    ky = item / gx;
+    tile_id = item - ky * gx;
+  }
+}
+
 // GEMM row m -> (image, h, w) on the rowH x rowW pixel grid.  gfx950 has no integer division: `m / d` expands to ~25
 // vector instructions, four of them quarter-rate multiplies, and on the fp32 matrix pipe every vector instruction of
 // a tile's prologue is paid in full (tools/micro/mfma_valu.hip).  Below 2^22 (the fast kernels' launcher checks M) the
@@ -198,7 +219,7 @@ __device__ __forceinline__ void dj_store_full_tile(float* ubase, unsigned lane_b
 // bias / accumulate / ReLU / (atomic) store with an optional strided-pixel row map.
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void dj_igemm_epilogue(const DjIgemmParams& p, f32x16 (&acc)[BM / (32 * WM)][BN / (32 * WN)],
-                                                  float* smem, int tile_m, int m0, int n0) {
+                                                  float* smem, int tile_m, int m0, int n0, int ky) {
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -263,10 +284,10 @@ __device__ __forceinline__ void dj_igemm_epilogue(const DjIgemmParams& p, f32x16
     }
   }
 
-  float* const Cb = p.C + (size_t)blockIdx.y * p.slab_stride;
+  float* const Cb = p.C + (size_t)ky * p.slab_stride;   // ky: this workgroup's K chunk
   if (p.cmap == 0 && m0 + BM <= p.M && n0 + BN <= p.N) {
     float bv[TN];
-    const bool add_bias = p.bias && (!p.atomic || blockIdx.y == 0);
+    const bool add_bias = p.bias && (!p.atomic || ky == 0);
 #pragma unroll
     for (int j = 0; j < TN; ++j) bv[j] = add_bias ? p.bias[n0 + (wn * TN + j) * 32 + l31] : 0.f;
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
@@ -298,7 +319,7 @@ __device__ __forceinline__ void dj_igemm_epilogue(const DjIgemmParams& p, f32x16
         float v = acc[i][j][r];
         float* dst = Cb + rowoff + n;
         if (p.atomic) {
-          if (p.bias && blockIdx.y == 0) v += p.bias[n];
+          if (p.bias && ky == 0) v += p.bias[n];
           atomicAdd(dst, v);
         } else {
           if (p.bias) v += p.bias[n];
@@ -691,5 +712,5 @@ __global__ __launch_bounds__(256) void dj_igemm_kernel(const DjIgemmParams p) {
     buf ^= 1;
   }
 
-  dj_igemm_epilogue<BM, BN, WM, WN>(p, acc, smem, tile_m, m0, n0);
+  dj_igemm_epilogue<BM, BN, WM, WN>(p, acc, smem, tile_m, m0, n0, (int)blockIdx.y);
 }

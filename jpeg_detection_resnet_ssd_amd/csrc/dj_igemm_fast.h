@@ -86,21 +86,14 @@ __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmPa
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blockIdx.x % 8 labels the XCD group),
-  // each XCD has its own L2.  Give every XCD a CONTIGUOUS run of the tile list (column tiles of one row tile are
-  // adjacent), so the A rows shared by those column tiles are fetched into one L2 instead of eight.  Bijective for
-  // any grid size; placement only affects speed.
+  // XCD-aware order of (tile, K chunk): dj_tile_of_workgroup (dj_igemm.h)
   const int tiles_n = (p.N + BN - 1) / BN;
-  int tile_id;
-  {
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, slot = b >> 3;
-    tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-  }
+  int tile_id, ky;
+  dj_tile_of_workgroup(tile_id, ky);
   const int tile_m = tile_id / tiles_n;
   const int tile_n = tile_id - tile_m * tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int kbeg0 = blockIdx.y * p.kchunk;
+  const int kbeg0 = ky * p.kchunk;
   const int kend = min(p.K, kbeg0 + p.kchunk);
   const int nk_all = (kend - kbeg0 + DJ_BK - 1) / DJ_BK;
   // group kg takes K-steps kg, kg + KS, ...; every group runs the same number of loop iterations (barriers match),
@@ -660,5 +653,5 @@ __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmPa
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * TN + j) * 16 + r) * 256 + tid];
   }
-  dj_igemm_epilogue<BM, BN, WM, WN>(p, acc, smem_base, tile_m, m0, n0);
+  dj_igemm_epilogue<BM, BN, WM, WN>(p, acc, smem_base, tile_m, m0, n0, ky);
 }

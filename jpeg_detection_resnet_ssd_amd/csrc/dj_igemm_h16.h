@@ -80,16 +80,12 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
   const int l31 = lane & 31, lh = lane >> 5;
 
   const int tiles_n = (p.N + BN - 1) / BN;
-  int tile_id;
-  {
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, slot = b >> 3;
-    tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-  }
+  int tile_id, ky;
+  dj_tile_of_workgroup(tile_id, ky);   // XCD-aware order of (tile, K chunk), dj_igemm.h
   const int tile_m = tile_id / tiles_n;
   const int tile_n = tile_id - tile_m * tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int kbeg = blockIdx.y * p.kchunk;
+  const int kbeg = ky * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
   const int nk = (kend - kbeg + BK - 1) / BK;
 
@@ -386,5 +382,5 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
   } else {
     for (int kt = 0; kt < nk; ++kt) kstep(r0, r0, kt, kbeg + (kt + 1) * BK, kt + 1 < nk);
   }
-  dj_igemm_epilogue<BM, BN, 2, 2>(p, acc, smem_base, tile_m, m0, n0);
+  dj_igemm_epilogue<BM, BN, 2, 2>(p, acc, smem_base, tile_m, m0, n0, ky);
 }

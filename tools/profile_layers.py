@@ -27,6 +27,18 @@ def wrap(name):
 for n in ("conv2d_fwd", "conv2d_fwd_addrelu", "conv2d_dgrad", "conv2d_wgrad"): wrap(n)
 plan.side_enabled = False      # one stream: an event pair brackets its launch alone
 model.run_train_step(plan); torch.cuda.synchronize()
+if os.environ.get("PROFILE_LAYERS_JSON"):
+    # the implicit-GEMM calls of one step in issue order, with their algorithmic bytes (each operand read once, the
+    # result written once): tools/pmc_layers.py joins this with per-dispatch rocprofv3 counters
+    import json
+    def alg_bytes(name, k):
+        b, ih, iw, ci, oh, co, kk, st, dil = k
+        ow = oh * iw // ih if ih == iw else oh
+        xin, yout, wt = b * ih * iw * ci, b * oh * ow * co, kk * kk * ci * co
+        extra = 2 * xin if name == "conv2d_fwd_addrelu" else 0     # residual operand read, sum written
+        return 4 * (xin + yout + wt + extra)
+    json.dump([dict(op=n, key=list(k), ms=e0.elapsed_time(e1), flop=fl, bytes=alg_bytes(n, k)) for n, k, e0, e1, fl in recs],
+              open(os.environ["PROFILE_LAYERS_JSON"], "w"))
 agg = collections.OrderedDict()
 for name, key, e0, e1, fl in recs:
     k = (name, key)
