@@ -94,6 +94,18 @@ long dj_conv2d_fwd_workspace_floats(const dj_conv2d_desc* d, int may_split_stats
 #define DJ_DGRAD_NO_SPLIT 2
 int dj_conv2d_nhwc_dgrad(const dj_conv2d_desc* d, const float* dy, const float* w, const float* bias,
                          float* dx, int beta, void* stream);
+/* Input gradient + the BatchNormalization BACKWARD statistics of the tensor it produces, in one launch.  dx here is
+ * g = dL/d relu(bn(z)) for the BatchNormalization layer whose ONLY consumer is this convolution
+ * (L/models/keras_ssd300_dct_j2d_resnet.py:77-96: conv -> BatchNormalization -> Activation('relu') -> conv inside the
+ * bottleneck blocks); z [batch*in_h*in_w][ld_z] is that layer's input, mean / invstd its saved batch statistics, scale /
+ * shift its affine (both NULL: no ReLU behind it, nothing is masked).  Besides storing dx the epilogue writes
+ *   partial[r][0][c] = sum g_m,   partial[r][1][c] = sum g_m * (z - mean[c]) * invstd[c],   g_m = g where z*scale+shift > 0
+ * over rows 64 r .. 64 r + 63, partial = [ceil(batch*in_h*in_w / 64)][2][in_c]: what dj_bn_bwd_reduce(mask_mode 2 / 0)
+ * computes in a pass of its own over g and z, in the layout dj_bn_bwd_finalize reads.  Never split over K, never
+ * accumulating; not for strided 1x1 convolutions (their dx is scattered). */
+int dj_conv2d_nhwc_dgrad_bnbwd(const dj_conv2d_desc* d, const float* dy, const float* w, float* dx, const float* z, int ld_z,
+                               const float* mean, const float* invstd, const float* scale, const float* shift,
+                               float* partial, void* stream);
 
 /* Residual Add + ReLU evaluated inside the consumer (the first 1x1 conv of the next bottleneck block,
  * L/models/keras_ssd300_dct_j2d_resnet.py:96-99 then :66-68): the conv's input is

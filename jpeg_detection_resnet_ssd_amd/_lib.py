@@ -69,6 +69,7 @@ SIGNATURES = {
     "dj_conv2d_nhwc_fwd_ws": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, FP, c_int, c_int, FP, FP, c_long, c_void_p]),
     "dj_conv2d_fwd_workspace_floats": (c_long, [POINTER(ConvDesc), c_int]),
     "dj_conv2d_nhwc_dgrad": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, c_int, c_void_p]),
+    "dj_conv2d_nhwc_dgrad_bnbwd": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, c_int, FP, FP, FP, FP, FP, c_void_p]),
     "dj_conv2d_nhwc_wgrad": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, c_int, c_int, c_void_p]),
     "dj_conv2d_fwd_addrelu_supported": (c_int, [POINTER(ConvDesc)]),
     "dj_conv2d_nhwc_fwd_addrelu": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, FP, FP, c_int, FP, FP, FP, c_int, c_int, FP,

@@ -531,8 +531,18 @@ extern "C" int dj_conv2d_nhwc_fwd_addrelu_ws(const dj_conv2d_desc* d, const floa
                                relu, stats, workspace, workspace_floats, stream);
 }
 
-extern "C" int dj_conv2d_nhwc_dgrad(const dj_conv2d_desc* d, const float* dy, const float* w, const float* bias,
-                                    float* dx, int beta, void* stream) {
+struct DgradBnBwd {   // dj_conv2d_nhwc_dgrad_bnbwd: see include/dj_hip.h
+  const float* z;
+  int ld_z;
+  const float* mean;
+  const float* invstd;
+  const float* scale;
+  const float* shift;
+  float* partial;
+};
+
+static int conv_dgrad_impl(const dj_conv2d_desc* d, const float* dy, const float* w, const float* bias, float* dx, int beta,
+                           const DgradBnBwd* bnb, void* stream) {
   if (int rc = check_desc(d)) return rc;
   DJ_CHECK_ARG(dy && w && dx, "conv dgrad: null tensor");
   const bool one_k_range = (beta & DJ_DGRAD_NO_SPLIT) != 0;   // no split-K: no arrival-order arithmetic
@@ -540,6 +550,15 @@ extern "C" int dj_conv2d_nhwc_dgrad(const dj_conv2d_desc* d, const float* dy, co
   hipStream_t s = (hipStream_t)stream;
   DjIgemmParams p;
   memset(&p, 0, sizeof(p));
+  if (bnb) {
+    p.bnb_z = bnb->z;
+    p.bnb_ldz = bnb->ld_z;
+    p.bnb_mean = bnb->mean;
+    p.bnb_invstd = bnb->invstd;
+    p.bnb_scale = bnb->scale;
+    p.bnb_shift = bnb->shift;
+    p.stats = bnb->partial;
+  }
   p.A = dy;
   p.B = w;
   p.C = dx;
@@ -559,6 +578,7 @@ extern "C" int dj_conv2d_nhwc_dgrad(const dj_conv2d_desc* d, const float* dy, co
   bool strided_1x1 = d->kernel_h == 1 && d->kernel_w == 1 && d->pad_top == 0 && d->pad_left == 0 &&
                      (d->stride_h > 1 || d->stride_w > 1) && d->stride_h == d->stride_w && bias == nullptr;
   int splits = 1;
+  DJ_CHECK_ARG(!(bnb && strided_1x1), "conv dgrad + BN backward statistics: not for strided 1x1 convolutions");
   if (strided_1x1) {
     // compact GEMM over the output grid, rows scattered to the strided input pixels
     p.M = d->batch * d->out_h * d->out_w;
@@ -614,6 +634,22 @@ extern "C" int dj_conv2d_nhwc_dgrad(const dj_conv2d_desc* d, const float* dy, co
     p.beta = 0;
   }
   return dj_launch_cfg<1, 1>(cfg, p, splits, s);
+}
+
+extern "C" int dj_conv2d_nhwc_dgrad(const dj_conv2d_desc* d, const float* dy, const float* w, const float* bias,
+                                    float* dx, int beta, void* stream) {
+  return conv_dgrad_impl(d, dy, w, bias, dx, beta, nullptr, stream);
+}
+
+extern "C" int dj_conv2d_nhwc_dgrad_bnbwd(const dj_conv2d_desc* d, const float* dy, const float* w, float* dx, const float* z,
+                                          int ld_z, const float* mean, const float* invstd, const float* scale,
+                                          const float* shift, float* partial, void* stream) {
+  DJ_CHECK_ARG(z && mean && invstd && partial, "conv dgrad + BN backward statistics: null tensor");
+  DJ_CHECK_ARG((scale == nullptr) == (shift == nullptr), "conv dgrad + BN backward statistics: scale/shift must come together");
+  DJ_CHECK_ARG(d && ld_z >= d->in_c, "conv dgrad + BN backward statistics: ld_z < in_c");
+  DgradBnBwd b{z, ld_z, mean, invstd, scale, shift, partial};
+  // one K range per tile, no accumulation: the accumulator of a tile IS the gradient the statistics are taken of
+  return conv_dgrad_impl(d, dy, w, nullptr, dx, DJ_DGRAD_NO_SPLIT, &b, stream);
 }
 
 extern "C" int dj_conv2d_nhwc_wgrad(const dj_conv2d_desc* d, const float* x, const float* dy, float* dw,

@@ -74,6 +74,16 @@ struct DjIgemmParams {
   float* bn_save_invstd;
   float bn_eps, bn_momentum;
   double bn_count;
+  // BatchNormalization BACKWARD statistics taken where the incoming gradient is produced: this GEMM is the input
+  // gradient g = dL/d relu(bn(z)) of the (only) consumer of that BatchNormalization, and its epilogue writes, per 64 rows
+  // and column, sum(g_m) and sum(g_m * (z - mean) * invstd) with g_m = g where z*scale+shift > 0 (else 0) to `stats` --
+  // the partial rows dj_bn_bwd_finalize reads; the separate pass over g and z (dj_bn_bwd_reduce) disappears
+  const float* bnb_z;       // [M][bnb_ldz]: input of that BatchNormalization (raw conv output); null: off
+  int bnb_ldz;
+  const float* bnb_mean;    // [N]
+  const float* bnb_invstd;
+  const float* bnb_scale;   // [N] or null (no ReLU behind the BatchNormalization: nothing is masked)
+  const float* bnb_shift;
 };
 
 template <int BM, int BN, int WM, int WN, int AM, int BMD>
@@ -231,6 +241,31 @@ __device__ __forceinline__ void dj_igemm_epilogue(const DjIgemmParams& p, f32x16
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       float s = 0.f, q = 0.f;
+      if (p.bnb_z) {
+        // BatchNormalization backward statistics of the gradient tile (see DjIgemmParams::bnb_z); rows / columns past
+        // the GEMM carry zero accumulators and are not read
+        const int n = n0 + (wn * TN + j) * 32 + l31;
+        const bool nok = n < p.N;
+        const float mu = nok ? p.bnb_mean[n] : 0.f, is = nok ? p.bnb_invstd[n] : 0.f;
+        const bool masked = p.bnb_scale != nullptr;
+        const float sc = (masked && nok) ? p.bnb_scale[n] : 0.f, sh = (masked && nok) ? p.bnb_shift[n] : 1.f;
+        const float* zc = p.bnb_z + n;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          float zz[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            zz[r] = (nok && m < p.M) ? zc[(size_t)m * p.bnb_ldz] : 0.f;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float g = (zz[r] * sc + sh > 0.f) ? acc[i][j][r] : 0.f;
+            s += g;
+            q += g * (zz[r] - mu) * is;
+          }
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -239,6 +274,7 @@ __device__ __forceinline__ void dj_igemm_epilogue(const DjIgemmParams& p, f32x16
           s += v;
           q += v * v;
         }
+      }
       s += __shfl_xor(s, 32);
       q += __shfl_xor(q, 32);
       if (lh == 0) {

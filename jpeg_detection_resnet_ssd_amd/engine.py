@@ -198,6 +198,8 @@ class GradRef(object):
         # (buffer, beta): whoever applies the mask must also store (beta 0) / accumulate (beta 1) the masked gradient
         # there -- the identity shortcut of a residual block shares it with the BatchNormalization branch
         self.also = also
+        # (partial rows, count): the BatchNormalization backward statistics of this gradient, taken by the GEMM that wrote it
+        self.bwd_partial = None
 
 
 class Value(object):

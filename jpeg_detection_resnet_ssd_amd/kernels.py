@@ -162,6 +162,20 @@ def conv2d_dgrad(desc, dy, w, dx, bias=None, beta=False, no_split=False):
     return dx
 
 
+def conv2d_dgrad_bnbwd(desc, dy, w, dx, z, mean, invstd, scale, shift, partial):
+    """Input gradient + BatchNormalization backward statistics of dx in the same launch (dj_conv2d_nhwc_dgrad_bnbwd):
+    `partial` [ceil(rows / 64)][2][in_c] receives what dj_bn_bwd_reduce would compute from (dx, z)."""
+    d = _desc_for(desc, dx, dy)
+    assert w.is_contiguous() and tuple(w.shape) == (d.kernel_h, d.kernel_w, d.in_c, d.out_c)
+    assert tuple(z.shape) == tuple(dx.shape)
+    rows = d.batch * d.in_h * d.in_w
+    assert partial.is_contiguous() and tuple(partial.shape) == ((rows + 63) // 64, 2, d.in_c)
+    check(_lib.load().dj_conv2d_nhwc_dgrad_bnbwd(d, ptr(dy), ptr(w), ptr(dx), ptr(z), _pixel_ld(z), ptr(mean), ptr(invstd),
+                                                 ptr(scale), ptr(shift), ptr(partial), _stream()),
+          "dj_conv2d_nhwc_dgrad_bnbwd")
+    return dx
+
+
 def conv2d_wgrad(desc, x, dy, dw, pro_scale=None, pro_shift=None, pro_relu=False, dw_zeroed=False):
     d = _desc_for(desc, x, dy)
     assert dw.is_contiguous() and tuple(dw.shape) == (d.kernel_h, d.kernel_w, d.in_c, d.out_c)

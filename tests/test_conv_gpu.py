@@ -372,3 +372,54 @@ def test_fwd_with_fused_batchnorm_finalize(geom, cuda):
         assert (mm - (0.0 * 0.99 + ref[2] * 0.01) * (1 + 0.99)).abs().max() <= 1e-5 * ref[2].abs().max() + 1e-7, cfg
         assert int(ticket.item()) == 0 and float(acc.abs().max()) == 0.0, cfg
     _lib.check(lib.dj_conv2d_tune_set(4, desc, -1, 1), "tune_set")
+
+
+@pytest.mark.parametrize("geom", [(3, 19, 19, 192, 256, 3, "same"), (2, 38, 38, 128, 512, 1, "valid"),
+                                  (5, 10, 10, 320, 128, 3, "same"), (1, 5, 5, 64, 96, 1, "valid")])
+@pytest.mark.parametrize("masked", [True, False])
+def test_dgrad_takes_bn_backward_statistics(geom, masked, cuda):
+    """dj_conv2d_nhwc_dgrad_bnbwd: the input gradient g of a convolution whose input is relu(bn(z)) (or bn(z)) and, from the
+    same launch, the BatchNormalization backward sums over g and z -- every tile variant; dx identical to the plain
+    launch, column totals of the partial rows against fp64 and against dj_bn_bwd_reduce on the stored dx."""
+    from jpeg_detection_resnet_ssd_amd import _lib, engine
+    from jpeg_detection_resnet_ssd_amd import kernels as K
+    lib = _lib.load()
+    b, h, w, ci, co, k, pad = geom
+    g = torch.Generator().manual_seed(11)
+    z = torch.randn(b, h, w, ci, generator=g)
+    wt = torch.randn(k, k, ci, co, generator=g) * (2.0 / (k * k * ci)) ** 0.5
+    desc = K.make_conv_desc(b, h, w, ci, co, (k, k), (1, 1), pad, (1, 1))
+    dy = torch.randn(b, desc.out_h, desc.out_w, co, generator=g)
+    mean, invstd = torch.randn(ci, generator=g) * 0.3, torch.rand(ci, generator=g) + 0.5
+    sc, sh = torch.rand(ci, generator=g) + 0.5, torch.randn(ci, generator=g) * 0.5
+    zd, wd, dyd, md, isd, scd, shd = [t.to(cuda) for t in (z, wt, dy, mean, invstd, sc, sh)]
+    rows = b * h * w
+    dx_ref = torch.empty(b, h, w, ci, device=cuda)
+    _lib.check(lib.dj_conv2d_tune_set(1, desc, 0, 1), "tune_set")
+    K.conv2d_dgrad(desc, dyd, wd, dx_ref)
+    gm = dx_ref.cpu().double().reshape(rows, ci)
+    z2 = z.double().reshape(rows, ci)
+    if masked:
+        gm = torch.where(z2 * sc.double() + sh.double() > 0, gm, torch.zeros_like(gm))
+    want0, want1 = gm.sum(0), (gm * (z2 - mean.double()) * invstd.double()).sum(0)
+    nr2 = engine.query("dj_reduce_rows", rows)
+    part2 = torch.empty(nr2, 2, ci, device=cuda)
+    engine.call("dj_bn_bwd_reduce", dx_ref, ci, zd, ci, None, 0, md, isd, scd, shd, 2 if masked else 0, rows, ci, part2)
+    try:
+        for cfg in range(lib.dj_conv2d_tune_configs()):
+            _lib.check(lib.dj_conv2d_tune_set(1, desc, cfg, 2), "tune_set")     # a registered split is overridden
+            dx = torch.full((b, h, w, ci), float("nan"), device=cuda)
+            part = torch.full(((rows + 63) // 64, 2, ci), float("nan"), device=cuda)
+            K.conv2d_dgrad_bnbwd(desc, dyd, wd, dx, zd, md, isd, scd if masked else None, shd if masked else None, part)
+            torch.cuda.synchronize()
+            tag = "cfg %d" % cfg
+            assert (dx.cpu().double() - dx_ref.cpu().double()).abs().max() <= _tol(dx_ref.cpu().double()), tag
+            got = part.cpu().double()
+            assert torch.isfinite(got).all(), tag
+            for slot, want in ((0, want0), (1, want1)):
+                err = (got[:, slot].sum(0) - want).abs().max()
+                assert err <= 1e-4 * float(want.abs().max()) + 1e-3, (tag, slot, float(err))
+                ref2 = part2.cpu().double()[:, slot].sum(0)
+                assert (got[:, slot].sum(0) - ref2).abs().max() <= 1e-4 * float(want.abs().max()) + 1e-3, (tag, slot)
+    finally:
+        _lib.check(lib.dj_conv2d_tune_set(1, desc, -1, 1), "tune_set")
