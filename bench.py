@@ -55,11 +55,16 @@ def measure_conv_kernels(model, plan):
             e0.record()
             r = f(desc, *a, **kw)
             e1.record()
-            records.append((e0, e1, conv_flops(desc), conv_bytes(desc)))
+            extra = 0.0
+            if name == "conv2d_dgrad_bnbwd":     # the BatchNormalization input z is read beside the GEMM operands
+                extra = 4.0 * desc.batch * desc.in_h * desc.in_w * desc.in_c
+            elif name == "conv2d_fwd_addrelu":   # residual operand read, the sum written
+                extra = 8.0 * desc.batch * desc.in_h * desc.in_w * desc.in_c
+            records.append((e0, e1, conv_flops(desc), conv_bytes(desc) + extra))
             return r
         setattr(Kn, name, timed)
 
-    for n in ("conv2d_fwd", "conv2d_fwd_addrelu", "conv2d_dgrad", "conv2d_wgrad"):
+    for n in ("conv2d_fwd", "conv2d_fwd_addrelu", "conv2d_dgrad", "conv2d_dgrad_bnbwd", "conv2d_wgrad"):
         wrap(n)
     try:
         plan.side_enabled = False      # one stream: a launch's events bracket that launch alone

@@ -24,7 +24,7 @@ def wrap(name):
                      2.0 * desc.batch * desc.out_h * desc.out_w * desc.out_c * desc.kernel_h * desc.kernel_w * desc.in_c))
         return r
     setattr(Kn, name, timed)
-for n in ("conv2d_fwd", "conv2d_fwd_addrelu", "conv2d_dgrad", "conv2d_wgrad"): wrap(n)
+for n in ("conv2d_fwd", "conv2d_fwd_addrelu", "conv2d_dgrad", "conv2d_dgrad_bnbwd", "conv2d_wgrad"): wrap(n)
 plan.side_enabled = False      # one stream: an event pair brackets its launch alone
 model.run_train_step(plan); torch.cuda.synchronize()
 if os.environ.get("PROFILE_LAYERS_JSON"):
@@ -36,6 +36,8 @@ if os.environ.get("PROFILE_LAYERS_JSON"):
         ow = oh * iw // ih if ih == iw else oh
         xin, yout, wt = b * ih * iw * ci, b * oh * ow * co, kk * kk * ci * co
         extra = 2 * xin if name == "conv2d_fwd_addrelu" else 0     # residual operand read, sum written
+        if name == "conv2d_dgrad_bnbwd":
+            extra = xin                                            # z of the BatchNormalization whose statistics it takes
         return 4 * (xin + yout + wt + extra)
     json.dump([dict(op=n, key=list(k), ms=e0.elapsed_time(e1), flop=fl, bytes=alg_bytes(n, k)) for n, k, e0, e1, fl in recs],
               open(os.environ["PROFILE_LAYERS_JSON"], "w"))
@@ -49,9 +51,10 @@ print("total conv ms %.2f, TF %.1f" % (tot, sum(a[2] for a in agg.values()) / to
 print("%-13s %-44s %4s %8s %7s %6s" % ("op", "B,H,W,Cin,OH,Cout,k,s,d", "n", "ms", "TF", "%"))
 for (name, key), a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("%-13s %-44s %4d %8.3f %7.1f %6.1f" % (name, str(key), a[0], a[1], a[2] / a[1] / 1e9, 100 * a[1] / tot))
-for d in ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad"):
-    t = sum(a[1] for (n, k), a in agg.items() if n == d); f = sum(a[2] for (n, k), a in agg.items() if n == d)
-    print("%s: %.2f ms, %.1f TF, %d launches" % (d, t, f / t / 1e9, sum(a[0] for (n, k), a in agg.items() if n == d)))
+for d in ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad"):      # (conv2d_fwd_addrelu, conv2d_dgrad_bnbwd count with their direction)
+    sel = [a for (n, k), a in agg.items() if n.startswith(d)]
+    t = sum(a[1] for a in sel); f = sum(a[2] for a in sel)
+    print("%s: %.2f ms, %.1f TF, %d launches" % (d, t, f / t / 1e9, sum(a[0] for a in sel)))
 ideal = sum(a[2] for a in agg.values()) / 130e9
 print("time above 130 TF/s pace: %.2f ms of %.2f" % (tot - ideal, tot))
 lost = sorted(((a[1] - a[2] / 130e9, n, k, a[0]) for (n, k), a in agg.items()), reverse=True)[:25]
