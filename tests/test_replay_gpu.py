@@ -169,6 +169,35 @@ class Replay(object):
             self._note("dgrad", key[1:], dx_l2=_rel_l2(got, ref), dx_max=_rel_max(got, ref))
         return run
 
+    def dgrad_bnbwd(self, orig):
+        """Input gradient whose epilogue also takes the BatchNormalization backward sums of the tensor it writes
+        (dj_conv2d_nhwc_dgrad_bnbwd): dx against the oracle, the column totals of the partial rows against fp64 sums over
+        (dx, z) on their natural scale.  (dgamma / dbeta / dz of that layer are checked again where its apply pass runs.)"""
+        def run(desc, dy, w, dx, z, mean, invstd, scale, shift, partial):
+            key = ("dgrad", self._geom(desc), "bnbwd", scale is not None)
+            if key in self.seen:
+                return orig(desc, dy, w, dx, z, mean, invstd, scale, shift, partial)
+            self.seen.add(key)
+            orig(desc, dy, w, dx, z, mean, invstd, scale, shift, partial)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            x0 = torch.zeros(tuple(dx.shape), dtype=torch.float64, requires_grad=True)
+            _oracle_conv(x0, _f64(w), None, desc).backward(_f64(dy))
+            c = dx.shape[-1]
+            g, zz = _f64(dx).reshape(-1, c), _f64(z).reshape(-1, c)
+            if scale is not None:
+                g = g * ((zz * _f64(scale) + _f64(shift)) > 0).to(torch.float64)
+            want0, want1 = g.sum(0), (g * (zz - _f64(mean)) * _f64(invstd)).sum(0)
+            got = _f64(partial).sum(0)
+            n_rows = float(g.shape[0])
+            nat0 = (n_rows ** 0.5) * g.norm(dim=0).clamp_min(1e-300)
+            nat1 = (n_rows ** 0.5) * (g * (zz - _f64(mean)) * _f64(invstd)).norm(dim=0).clamp_min(1e-300)
+            self.cpu_s += time.time() - t0
+            self._note("dgrad", key[1:], dx_l2=_rel_l2(_f64(dx), x0.grad), dx_max=_rel_max(_f64(dx), x0.grad),
+                       sum_g_nat=float(((got[0] - want0).abs() / nat0).max()),
+                       sum_gxhat_nat=float(((got[1] - want1).abs() / nat1).max()))
+        return run
+
     def wgrad(self, orig):
         def run(desc, x, dy, dw, pro_scale=None, pro_shift=None, pro_relu=False, dw_zeroed=False):
             key = ("wgrad", self._geom(desc), pro_scale is not None, bool(pro_relu), bool(dw_zeroed))
@@ -289,6 +318,7 @@ def test_every_distinct_launch_of_the_benched_step_matches_the_oracle(cuda, monk
     monkeypatch.setattr(Kn, "conv2d_fwd", rp.fwd(Kn.conv2d_fwd))
     monkeypatch.setattr(Kn, "conv2d_fwd_addrelu", rp.fwd_addrelu(Kn.conv2d_fwd_addrelu))
     monkeypatch.setattr(Kn, "conv2d_dgrad", rp.dgrad(Kn.conv2d_dgrad))
+    monkeypatch.setattr(Kn, "conv2d_dgrad_bnbwd", rp.dgrad_bnbwd(Kn.conv2d_dgrad_bnbwd))
     monkeypatch.setattr(Kn, "conv2d_wgrad", rp.wgrad(Kn.conv2d_wgrad))
     monkeypatch.setattr(L, "call", rp.call(L.call))
     t0 = time.time()
@@ -310,6 +340,8 @@ def test_every_distinct_launch_of_the_benched_step_matches_the_oracle(cuda, monk
     # the deconv SSD300 graph: 76 convolutions + 2 transposed ones, 53 BatchNormalization layers
     assert n_kind["fwd"] >= 25 and n_kind["dgrad"] >= 25 and n_kind["wgrad"] >= 30 and n_kind["bn"] >= 10, n_kind
     assert n_kind["fwd_addrelu"] >= 3, n_kind
+    # the conv -> BN -> ReLU -> conv chains of the bottleneck blocks take the BatchNormalization backward sums in the GEMM
+    assert sum(1 for s in rp.seen if s[0] == "dgrad" and "bnbwd" in s) >= 5, sorted(s for s in rp.seen if s[0] == "dgrad")
     # sums measured on their natural scale: fp32 partial sums in double totals stay below 1e-5 of it (measured 9e-6 on
     # a ReLU-masked layer, where the fp64 oracle and the fp32 engine disagree on the sign of a few pre-activations)
     bad = [(kind, geom, metric, value) for kind, geom, metric, value in rp.rows
