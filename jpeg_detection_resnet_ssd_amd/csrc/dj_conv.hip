@@ -553,6 +553,8 @@ static int conv_dgrad_impl(const dj_conv2d_desc* d, const float* dy, const float
   if (bnb) {
     p.bnb_z = bnb->z;
     p.bnb_ldz = bnb->ld_z;
+    p.bnb_zbytes = extent_bytes((long)d->batch * d->in_h * d->in_w, bnb->ld_z, d->in_c);
+    DJ_CHECK_ARG(p.bnb_zbytes > 0, "conv dgrad + BN backward statistics: z of 2 GiB or more");
     p.bnb_mean = bnb->mean;
     p.bnb_invstd = bnb->invstd;
     p.bnb_scale = bnb->scale;

@@ -52,11 +52,40 @@ static int launch_kernel(KernT kern, int smem_bytes, int bm, int bn, const DjIge
   return DJ_OK;
 }
 
+// One launch site per kernel instantiation; an input-gradient launch that asks for BatchNormalization backward statistics
+// (p.bnb_z) takes the EPI = 1 twin of the same variant.
+template <int BM, int BN, int WM, int WN, int AM, int BMD, int PRO, int NSTAGE, int PREC, int KS, int NP>
+static int launch_fast(int smem_bytes, const DjIgemmParams& p, int splits, hipStream_t s, int threads = 256) {
+  if constexpr (AM == 1 && BMD == 1 && PRO == 0) {   // (the input-gradient GEMM has no prologue)
+    if (p.bnb_z) {
+      static bool done1 = false;
+      return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, PRO, NSTAGE, PREC, KS, NP, 1>, smem_bytes, BM, BN, p,
+                           splits, s, &done1, threads);
+    }
+  }
+  static bool done0 = false;
+  return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, PRO, NSTAGE, PREC, KS, NP, 0>, smem_bytes, BM, BN, p, splits,
+                       s, &done0, threads);
+}
+
+template <int BM, int BN, int AM, int BMD, int PRO, int PREC, int BK, int PF>
+static int launch_h16_kernel(int smem_bytes, const DjIgemmParams& p, int splits, hipStream_t s) {
+  if constexpr (AM == 1 && BMD == 1 && PRO == 0) {
+    if (p.bnb_z) {
+      static bool done1 = false;
+      return launch_kernel(dj_igemm_h16_kernel<BM, BN, AM, BMD, PRO, PREC, BK, PF, 1>, smem_bytes, BM, BN, p, splits, s, &done1,
+                           256);
+    }
+  }
+  static bool done0 = false;
+  return launch_kernel(dj_igemm_h16_kernel<BM, BN, AM, BMD, PRO, PREC, BK, PF, 0>, smem_bytes, BM, BN, p, splits, s, &done0, 256);
+}
+
 // fast = 0: generic kernel; 1: branch-free kernel; 2: branch-free kernel with the affine prologue
 template <int BM, int BN, int WM, int WN, int AM, int BMD, int NSTAGE>
 static int launch_one(const DjIgemmParams& p, int splits, hipStream_t s, int fast) {
   using Cfg = DjIgemmCfg<BM, BN, WM, WN, AM, BMD>;
-  static bool done[3] = {false, false, false};
+  static bool done[1] = {false};
   const int smem_fast = Cfg::SMEM_BYTES / 2 * ((NSTAGE == 2 || NSTAGE == 4) ? 2 : 1);
   {
     // 1x1 kernels without padding: the variant that does no per-K-step bounds arithmetic (NP, see dj_igemm_fast.h); for
@@ -64,49 +93,36 @@ static int launch_one(const DjIgemmParams& p, int splits, hipStream_t s, int fas
     static const bool np_off = getenv("DJ_NO_NP") != nullptr;
     const bool same_grid = (AM != 2) || (p.sH == 1 && p.sW == 1 && p.rowH == p.srcH && p.rowW == p.srcW);
     if ((fast == 1 || fast == 2) && p.KH == 1 && p.KW == 1 && p.pT == 0 && p.pL == 0 && same_grid && !np_off) {
-      static bool npdone[2] = {false, false};
       if (fast == 1)
-        return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 0, NSTAGE, 0, 1, 1>, smem_fast, BM, BN, p, splits,
-                             s, &npdone[0]);
-      return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 1, NSTAGE, 0, 1, 1>, smem_fast, BM, BN, p, splits, s,
-                           &npdone[1]);
+        return launch_fast<BM, BN, WM, WN, AM, BMD, 0, NSTAGE, 0, 1, 1>(smem_fast, p, splits, s);
+      return launch_fast<BM, BN, WM, WN, AM, BMD, 1, NSTAGE, 0, 1, 1>(smem_fast, p, splits, s);
     }
     if constexpr (AM == 2) {
       // weight gradient with taps / padding / stride whose tiles lie under one tap each: incremental pixel walk (NP 3)
       static const bool walk_off = getenv("DJ_NO_WALK") != nullptr;
       if ((fast == 1 || fast == 2) && !np_off && !walk_off && p.srcC % BM == 0) {
-        static bool wkdone[2] = {false, false};
         if (fast == 1)
-          return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 0, NSTAGE, 0, 1, 3>, smem_fast, BM, BN, p, splits,
-                               s, &wkdone[0]);
-        return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 1, NSTAGE, 0, 1, 3>, smem_fast, BM, BN, p, splits, s,
-                             &wkdone[1]);
+          return launch_fast<BM, BN, WM, WN, AM, BMD, 0, NSTAGE, 0, 1, 3>(smem_fast, p, splits, s);
+        return launch_fast<BM, BN, WM, WN, AM, BMD, 1, NSTAGE, 0, 1, 3>(smem_fast, p, splits, s);
       }
     }
     if constexpr (AM != 2) {
       // kernels with taps / padding: per-tap row offsets cached across the K-steps of a tap (NP 2)
       static const bool ht_off = getenv("DJ_NO_TAPCACHE") != nullptr;
       if ((fast == 1 || fast == 2) && !np_off && !ht_off) {
-        static bool htdone[2] = {false, false};
         if (fast == 1)
-          return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 0, NSTAGE, 0, 1, 2>, smem_fast, BM, BN, p, splits,
-                               s, &htdone[0]);
-        return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 1, NSTAGE, 0, 1, 2>, smem_fast, BM, BN, p, splits, s,
-                             &htdone[1]);
+          return launch_fast<BM, BN, WM, WN, AM, BMD, 0, NSTAGE, 0, 1, 2>(smem_fast, p, splits, s);
+        return launch_fast<BM, BN, WM, WN, AM, BMD, 1, NSTAGE, 0, 1, 2>(smem_fast, p, splits, s);
       }
     }
   }
   if (fast == 1)
-    return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 0, NSTAGE>, smem_fast, BM, BN, p, splits, s,
-                         &done[1]);
+    return launch_fast<BM, BN, WM, WN, AM, BMD, 0, NSTAGE, 0, 1, 0>(smem_fast, p, splits, s);
   if (fast == 2)
-    return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 1, NSTAGE>, smem_fast, BM, BN, p, splits, s,
-                         &done[2]);
+    return launch_fast<BM, BN, WM, WN, AM, BMD, 1, NSTAGE, 0, 1, 0>(smem_fast, p, splits, s);
   if (fast == 3) {   // residual-add prologue: forward GEMM only
     if constexpr (AM == 0 && BMD == 0) {
-      static bool done3 = false;
-      return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, 3, NSTAGE>, smem_fast, BM, BN, p, splits, s,
-                           &done3);
+      return launch_fast<BM, BN, WM, WN, AM, BMD, 3, NSTAGE, 0, 1, 0>(smem_fast, p, splits, s);
     } else {
       dj_set_error("residual-add prologue outside the forward GEMM");
       return DJ_ERR_ARG;
@@ -119,22 +135,17 @@ static int launch_one(const DjIgemmParams& p, int splits, hipStream_t s, int fas
 template <int BM, int BN, int AM, int BMD>
 static int launch_k2(const DjIgemmParams& p, int splits, hipStream_t s, int fast) {
   using Cfg = DjIgemmCfg<BM, BN, 2, 2, AM, BMD>;
-  static bool done[2] = {false, false};
   if (fast == 1)
-    return launch_kernel(dj_igemm_fast_kernel<BM, BN, 2, 2, AM, BMD, 0, 4, 0, 2>, 2 * Cfg::SMEM_BYTES, BM, BN, p, splits, s,
-                         &done[0], 512);
+    return launch_fast<BM, BN, 2, 2, AM, BMD, 0, 4, 0, 2, 0>(2 * Cfg::SMEM_BYTES, p, splits, s, 512);
   if (fast == 3) {
     if constexpr (AM == 0 && BMD == 0) {
-      static bool done3 = false;
-      return launch_kernel(dj_igemm_fast_kernel<BM, BN, 2, 2, AM, BMD, 3, 4, 0, 2>, 2 * Cfg::SMEM_BYTES, BM, BN, p, splits,
-                           s, &done3, 512);
+      return launch_fast<BM, BN, 2, 2, AM, BMD, 3, 4, 0, 2, 0>(2 * Cfg::SMEM_BYTES, p, splits, s, 512);
     } else {
       dj_set_error("residual-add prologue outside the forward GEMM");
       return DJ_ERR_ARG;
     }
   }
-  return launch_kernel(dj_igemm_fast_kernel<BM, BN, 2, 2, AM, BMD, 1, 4, 0, 2>, 2 * Cfg::SMEM_BYTES, BM, BN, p, splits, s,
-                       &done[1], 512);
+  return launch_fast<BM, BN, 2, 2, AM, BMD, 1, 4, 0, 2, 0>(2 * Cfg::SMEM_BYTES, p, splits, s, 512);
 }
 
 #include <atomic>
@@ -169,21 +180,16 @@ static int launch_h16(const DjIgemmParams& p, int splits, hipStream_t s, int fas
   using H = DjH16Cfg<BM, BN, AM, BMD, BK>;
   if (fast == 3) {
     if constexpr (AM == 0 && BMD == 0) {
-      static bool hdone3 = false;
-      return launch_kernel(dj_igemm_h16_kernel<BM, BN, AM, BMD, 3, PREC, BK, PF>, H::SMEM_BYTES, BM, BN, p, splits, s,
-                           &hdone3);
+      return launch_h16_kernel<BM, BN, AM, BMD, 3, PREC, BK, PF>(H::SMEM_BYTES, p, splits, s);
     } else {
       dj_set_error("residual-add prologue outside the forward GEMM");
       return DJ_ERR_ARG;
     }
   }
-  static bool hdone[2] = {false, false};
   if (fast == 1)
-    return launch_kernel(dj_igemm_h16_kernel<BM, BN, AM, BMD, 0, PREC, BK, PF>, H::SMEM_BYTES, BM, BN, p, splits, s,
-                         &hdone[0]);
+    return launch_h16_kernel<BM, BN, AM, BMD, 0, PREC, BK, PF>(H::SMEM_BYTES, p, splits, s);
   if constexpr (AM != 1) {  // the input-gradient GEMM has no prologue
-    return launch_kernel(dj_igemm_h16_kernel<BM, BN, AM, BMD, 1, PREC, BK, PF>, H::SMEM_BYTES, BM, BN, p, splits, s,
-                         &hdone[1]);
+    return launch_h16_kernel<BM, BN, AM, BMD, 1, PREC, BK, PF>(H::SMEM_BYTES, p, splits, s);
   } else {
     dj_set_error("prologue on the input-gradient GEMM");
     return DJ_ERR_ARG;
@@ -203,33 +209,14 @@ static int launch_h16_depth(const DjIgemmParams& p, int splits, hipStream_t s, i
 
 template <int BM, int BN, int AM, int BMD, int PREC>
 static int launch_lowp(const DjIgemmParams& p, int splits, hipStream_t s, int fast, bool deep, bool pf2) {
-  using Cfg = DjIgemmCfg<BM, BN, 2, 2, AM, BMD>;
-  static bool done[2] = {false, false};
-  // 16-bit tiles in LDS + 16-deep MFMA (dj_igemm_h16.h); DJ_LOWP_LDS32=1 keeps the older path (fp32 tiles, fragments
-  // rounded at read time, 8-deep MFMA) for A/B runs
-  static const bool lds32 = getenv("DJ_LOWP_LDS32") != nullptr;
-  if (!lds32 && (fast == 1 || fast == 3 || (fast == 2 && AM != 1))) {
-    if constexpr (BM * BN < 128 * 128) {   // the 128x128 tile has no registers to spare for a second prefetch set
-      static const bool pf1 = getenv("DJ_H16_PF1") != nullptr;
-      if (pf2 && !pf1) return launch_h16_depth<BM, BN, AM, BMD, PREC, 2>(p, splits, s, fast, deep);
-    }
-    return launch_h16_depth<BM, BN, AM, BMD, PREC, 1>(p, splits, s, fast, deep);
+  // 16-bit tiles in LDS + 16-deep MFMA (dj_igemm_h16.h).  (The round-1 path -- fp32 tiles, fragments rounded at read time,
+  // 8-deep MFMA: PREC != 0 of dj_igemm_fast_kernel -- is no longer instantiated; it was kept for A/B runs until the end
+  // of round 2: 16.63 ms against 15.04 ms per fp16 step when the 16-bit tiles arrived.)
+  if constexpr (BM * BN < 128 * 128) {   // the 128x128 tile has no registers to spare for a second prefetch set
+    static const bool pf1 = getenv("DJ_H16_PF1") != nullptr;
+    if (pf2 && !pf1) return launch_h16_depth<BM, BN, AM, BMD, PREC, 2>(p, splits, s, fast, deep);
   }
-  if (fast == 1)
-    return launch_kernel(dj_igemm_fast_kernel<BM, BN, 2, 2, AM, BMD, 0, 2, PREC>, Cfg::SMEM_BYTES, BM, BN, p, splits, s,
-                         &done[0]);
-  if (fast == 3) {
-    if constexpr (AM == 0 && BMD == 0) {
-      static bool done3 = false;
-      return launch_kernel(dj_igemm_fast_kernel<BM, BN, 2, 2, AM, BMD, 3, 2, PREC>, Cfg::SMEM_BYTES, BM, BN, p, splits, s,
-                           &done3);
-    } else {
-      dj_set_error("residual-add prologue outside the forward GEMM");
-      return DJ_ERR_ARG;
-    }
-  }
-  return launch_kernel(dj_igemm_fast_kernel<BM, BN, 2, 2, AM, BMD, 1, 2, PREC>, Cfg::SMEM_BYTES, BM, BN, p, splits, s,
-                       &done[1]);
+  return launch_h16_depth<BM, BN, AM, BMD, PREC, 1>(p, splits, s, fast, deep);
 }
 
 // Reduced-precision variants behind the fourteen configuration indices of the tuner (the schedule variants of the fp32
@@ -255,8 +242,9 @@ int dj_launch_cfg(int cfg, const DjIgemmParams& p, int splits, hipStream_t s) {
   const int mode = dj_compute_mode();
   if (fast && mode != 0 && cfg >= 0 && cfg < N_CFG) {
     // A-mode 0 with B-mode 0 is the forward GEMM; everything else carries gradients
-    const bool forward = (AM == 0 && BMD == 0);
-    if (mode == 1 && forward) return launch_lowp_cfg<AM, BMD, 1>(cfg, p, splits, s, fast);
+    if constexpr (AM == 0 && BMD == 0) {   // (fp16 variants are instantiated for the forward GEMM only)
+      if (mode == 1) return launch_lowp_cfg<AM, BMD, 1>(cfg, p, splits, s, fast);
+    }
     return launch_lowp_cfg<AM, BMD, 2>(cfg, p, splits, s, fast);
   }
   switch (cfg) {

@@ -80,6 +80,7 @@ struct DjIgemmParams {
   // the partial rows dj_bn_bwd_finalize reads; the separate pass over g and z (dj_bn_bwd_reduce) disappears
   const float* bnb_z;       // [M][bnb_ldz]: input of that BatchNormalization (raw conv output); null: off
   int bnb_ldz;
+  int bnb_zbytes;           // byte extent of z, ((M - 1) * bnb_ldz + N) * 4 < 2 GiB, for the buffer descriptor
   const float* bnb_mean;    // [N]
   const float* bnb_invstd;
   const float* bnb_scale;   // [N] or null (no ReLU behind the BatchNormalization: nothing is masked)
@@ -227,7 +228,10 @@ __device__ __forceinline__ void dj_store_full_tile(float* ubase, unsigned lane_b
 
 // Shared epilogue: optional per-tile BatchNormalization statistics of the raw accumulator, then
 // bias / accumulate / ReLU / (atomic) store with an optional strided-pixel row map.
-template <int BM, int BN, int WM, int WN>
+// BNB: the kernel may be asked for BatchNormalization backward statistics (DjIgemmParams::bnb_z) -- only the
+// input-gradient GEMM is; compiled into every kernel the extra code and its six parameters cost the others registers
+// (128x128 forward variants 160 -> 180 VGPRs, i.e. three waves per SIMD -> two; the residual-add variants 26-42 SGPR spills)
+template <int BM, int BN, int WM, int WN, bool BNB = false>
 __device__ __forceinline__ void dj_igemm_epilogue(const DjIgemmParams& p, f32x16 (&acc)[BM / (32 * WM)][BN / (32 * WN)],
                                                   float* smem, int tile_m, int m0, int n0, int ky) {
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
@@ -241,7 +245,7 @@ __device__ __forceinline__ void dj_igemm_epilogue(const DjIgemmParams& p, f32x16
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       float s = 0.f, q = 0.f;
-      if (p.bnb_z) {
+      if (BNB && p.bnb_z) {
         // BatchNormalization backward statistics of the gradient tile (see DjIgemmParams::bnb_z); rows / columns past
         // the GEMM carry zero accumulators and are not read
         const int n = n0 + (wn * TN + j) * 32 + l31;
@@ -249,20 +253,31 @@ __device__ __forceinline__ void dj_igemm_epilogue(const DjIgemmParams& p, f32x16
         const float mu = nok ? p.bnb_mean[n] : 0.f, is = nok ? p.bnb_invstd[n] : 0.f;
         const bool masked = p.bnb_scale != nullptr;
         const float sc = (masked && nok) ? p.bnb_scale[n] : 0.f, sh = (masked && nok) ? p.bnb_shift[n] : 1.f;
-        const float* zc = p.bnb_z + n;
+        // z through a buffer descriptor, no guards around the loads (a guarded scalar load is an exec-mask save / restore
+        // and, as the compiler schedules it, one exposed memory latency per VALUE: the first version of this epilogue cost
+        // 28 us on a 2888-tile launch): rows past M lie past the descriptor's extent and read as zero; a column past N
+        // reads some other finite element of z into a lane whose accumulators are zero and whose sums are not stored
+        const __amdgpu_buffer_rsrc_t rZ = __builtin_amdgcn_make_buffer_rsrc((void*)p.bnb_z, 0, p.bnb_zbytes, 0x00020000);
+        const unsigned row_b = (unsigned)p.bnb_ldz * 4u;
+        // eight values at a time: left to itself the compiler issues all 16 * TM * TN loads of the tile first, and the
+        // registers that takes cost the whole kernel a wave per SIMD (128x128: 160 -> 184 VGPRs)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          float zz[16];
+          const unsigned lane_b = (unsigned)(m0 + (wm * TM + i) * 32 + 4 * lh) * row_b + (unsigned)n * 4u;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            zz[r] = (nok && m < p.M) ? zc[(size_t)m * p.bnb_ldz] : 0.f;
-          }
+          for (int h = 0; h < 2; ++h) {
+            float zz[8];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float g = (zz[r] * sc + sh > 0.f) ? acc[i][j][r] : 0.f;
-            s += g;
-            q += g * (zz[r] - mu) * is;
+            for (int r = 0; r < 8; ++r)
+              zz[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                    rZ, (int)(lane_b + (unsigned)((r & 3) + 8 * (2 * h + (r >> 2))) * row_b), 0, 0));
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              const float g = (zz[r] * sc + sh > 0.f) ? acc[i][j][8 * h + r] : 0.f;
+              s += g;
+              q += g * (zz[r] - mu) * is;
+            }
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       } else {
@@ -748,5 +763,5 @@ __global__ __launch_bounds__(256) void dj_igemm_kernel(const DjIgemmParams p) {
     buf ^= 1;
   }
 
-  dj_igemm_epilogue<BM, BN, WM, WN>(p, acc, smem, tile_m, m0, n0, (int)blockIdx.y);
+  dj_igemm_epilogue<BM, BN, WM, WN, (AM == 1 && BMD == 1)>(p, acc, smem, tile_m, m0, n0, (int)blockIdx.y);
 }

@@ -67,8 +67,13 @@ __device__ __forceinline__ dj_short4 dj_to_bf16x4(f32x4 v) {
 //       constants with two carries (row end, image end) -- ~15 vector instructions per K-step where the float-reciprocal
 //       decomposition, the per-chunk tap arithmetic and its three integer multiplies took ~75 (64x64 tile: 134 -> ~75
 //       per 16 MFMAs, and the multiplies are quarter rate).
-template <int BM, int BN, int WM, int WN, int AM, int BMD, int PRO, int NSTAGE = 2, int PREC = 0, int KS = 1, int NP = 0>
+// EPI: 1 = the epilogue also takes BatchNormalization backward statistics (DjIgemmParams::bnb_z; input-gradient GEMM only).
+//      An instantiation of its own: that code needs registers (eight z values in flight beside the accumulators) and the
+//      launches that do not ask for it keep their occupancy.
+template <int BM, int BN, int WM, int WN, int AM, int BMD, int PRO, int NSTAGE = 2, int PREC = 0, int KS = 1, int NP = 0,
+          int EPI = 0>
 __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmParams p) {
+  static_assert(EPI == 0 || (AM == 1 && BMD == 1), "BatchNormalization backward statistics: input-gradient GEMM only");
   static_assert(NP == 0 || (PRO != 3 && KS == 1), "NP: no residual-add prologue, no in-workgroup K split");
   static_assert(NP != 2 || AM != 2, "NP 2 (per-tap offsets) is for the k-contiguous A operand");
   static_assert(NP != 3 || AM == 2, "NP 3 (pixel walk) is for the weight gradient's gathered operand");
@@ -653,5 +658,5 @@ __global__ __launch_bounds__(256 * KS) void dj_igemm_fast_kernel(const DjIgemmPa
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * TN + j) * 16 + r) * 256 + tid];
   }
-  dj_igemm_epilogue<BM, BN, WM, WN>(p, acc, smem_base, tile_m, m0, n0, ky);
+  dj_igemm_epilogue<BM, BN, WM, WN, EPI == 1>(p, acc, smem_base, tile_m, m0, n0, ky);
 }

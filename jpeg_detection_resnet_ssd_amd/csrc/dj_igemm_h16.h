@@ -65,8 +65,10 @@ __device__ __forceinline__ dj_short4 dj_round4(f32x4 v) {
 // middle.  2: two register sets -- the loads of tile kt+2 are issued at the top of step kt, tile kt+1 (issued a whole
 // step earlier) goes to LDS: a load has a full K-step longer to land (small tiles, whose steps are short; costs one
 // more set of staging registers).
-template <int BM, int BN, int AM, int BMD, int PRO, int PREC, int BK = 32, int PF = 1>
+// EPI: 1 = the epilogue also takes BatchNormalization backward statistics (see dj_igemm_fast.h), input gradient only.
+template <int BM, int BN, int AM, int BMD, int PRO, int PREC, int BK = 32, int PF = 1, int EPI = 0>
 __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p) {
+  static_assert(EPI == 0 || (AM == 1 && BMD == 1), "BatchNormalization backward statistics: input-gradient GEMM only");
   using Cfg = DjH16Cfg<BM, BN, AM, BMD, BK>;
   constexpr int TM = Cfg::TM, TN = Cfg::TN, NA = Cfg::NA, NB = Cfg::NB;
   constexpr int PA = Cfg::PA, PB = Cfg::PB, KCH = Cfg::KCH, RPP = Cfg::RPP;
@@ -382,5 +384,5 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
   } else {
     for (int kt = 0; kt < nk; ++kt) kstep(r0, r0, kt, kbeg + (kt + 1) * BK, kt + 1 < nk);
   }
-  dj_igemm_epilogue<BM, BN, 2, 2>(p, acc, smem_base, tile_m, m0, n0, ky);
+  dj_igemm_epilogue<BM, BN, 2, 2, EPI == 1>(p, acc, smem_base, tile_m, m0, n0, ky);
 }
