@@ -36,6 +36,27 @@ def test_conv_desc_argument_errors_surface_through_the_abi():
         _lib.check(lib.dj_conv2d_fwd_stats_rows(ctypes.byref(d)), "stats_rows")
 
 
+def test_dgrad_with_bn_backward_statistics_refuses_what_it_cannot_do():
+    """dj_conv2d_nhwc_dgrad_bnbwd checks its arguments on the host, before any launch: missing tensors, scale without
+    shift, a z pitch below the channel count, and strided 1x1 convolutions (their dx is scattered, the accumulator tile is
+    not the gradient tile)."""
+    import ctypes
+    from jpeg_detection_resnet_ssd_amd import _lib
+    lib = _lib.load()
+    fake = 0x1000      # never dereferenced: every call below must fail in the argument checks
+    ok = _lib.ConvDesc(2, 8, 8, 32, 8, 8, 64, 3, 3, 1, 1, 1, 1, 1, 1, 32, 64)
+    call = lib.dj_conv2d_nhwc_dgrad_bnbwd
+    assert call(ctypes.byref(ok), fake, fake, fake, None, 32, fake, fake, fake, fake, fake, None) < 0
+    assert b"null" in lib.dj_last_error()
+    assert call(ctypes.byref(ok), fake, fake, fake, fake, 32, fake, fake, fake, None, fake, None) < 0
+    assert b"scale/shift" in lib.dj_last_error()
+    assert call(ctypes.byref(ok), fake, fake, fake, fake, 16, fake, fake, None, None, fake, None) < 0
+    assert b"ld_z" in lib.dj_last_error()
+    strided = _lib.ConvDesc(2, 8, 8, 32, 4, 4, 64, 1, 1, 2, 2, 1, 1, 0, 0, 32, 64)
+    assert call(ctypes.byref(strided), fake, fake, fake, fake, 32, fake, fake, None, None, fake, None) < 0
+    assert b"strided" in lib.dj_last_error()
+
+
 def test_same_padding_rule():
     from jpeg_detection_resnet_ssd_amd.kernels import conv_geometry, same_padding
     assert same_padding(38, 2, 1) == (0, 1, 38)        # even kernel: pad after only
