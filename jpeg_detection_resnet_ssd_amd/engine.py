@@ -477,7 +477,7 @@ class Plan(object):
             c0, s0 = ctypes.c_int(0), ctypes.c_int(1)
             check(lib.dj_conv2d_default_config(direction, desc, ctypes.byref(c0), ctypes.byref(s0)), "default_config")
             base = direction & 3
-            if direction & 4:
+            if direction & 4 or getattr(fn, "no_split", False):
                 split_opts = [1]
             elif base == 2:
                 kk = desc.batch * desc.out_h * desc.out_w

@@ -509,8 +509,10 @@ class Conv2D(Layer):
                     part = plan.empty(nr, 2, cin)
                     msc, msh = (x.scale, x.shift) if x.relu else (None, None)
                     zbuf = x.buf
-                    plan.emit_conv(1, desc, lambda: Kn.conv2d_dgrad_bnbwd(desc, dy, wgt, dx, zbuf, mean, invstd, msc, msh,
-                                                                          part), backward=True)
+                    def fused_dgrad():
+                        return Kn.conv2d_dgrad_bnbwd(desc, dy, wgt, dx, zbuf, mean, invstd, msc, msh, part)
+                    fused_dgrad.no_split = True      # for the tuners: a registered split-K factor is ignored here
+                    plan.emit_conv(1, desc, fused_dgrad, backward=True)
                     x.grad.bwd_partial = (part, nr)
                 else:
                     dx, beta = plan.grad_of(x, zeroed=own_memset and os.environ.get("DJ_ZERO_ARENA", "1") != "0")

@@ -73,6 +73,8 @@ for key, (direction, desc, count) in geoms.items():
     if (direction & 3) == 2 and plan.side_stream is not None and not (len(known) > 3 and known[3]):
         sp = max(1, (sp + 1) // 2)      # what Plan.autotune registered for a fastest-alone entry
     cur[key] = (cfg, sp, ms * count)
+# input gradients that take BatchNormalization backward statistics never split (their launch ignores a registered factor)
+unsplit = {(d,) + tuple(getattr(desc, n) for n in names) for d, desc, fn in plan.conv_calls if getattr(fn, "no_split", False)}
 protected = set()
 if protect:
     other, _ = workloads.build_ssd(protect)
@@ -111,7 +113,7 @@ for key in order:
     c = best[0][0] if best[0] is not None else cfg0
     if (direction & 3) == 2:
         sp_opts = {max(1, sp0 // 2), sp0 * 2}
-    elif direction in (0, 1):
+    elif direction in (0, 1) and key not in unsplit:
         sp_opts = {1, 2, 4, 8}
     else:
         sp_opts = set()
