@@ -49,7 +49,7 @@ def build_library(force=False, verbose=False):
                 raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(6, max(1, len(sources)))) as ex:
+    with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 6, 8, max(1, len(sources)))) as ex:
         objs = list(ex.map(compile_one, sources))
     if force or _newer(objs, LIB_PATH):
         cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs

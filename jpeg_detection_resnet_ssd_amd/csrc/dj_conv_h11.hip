@@ -1,0 +1,4 @@
+// Reduced-precision kernel instantiations of the input-gradient GEMM.
+#include "dj_conv_launch_h16.h"
+
+template int dj_launch_lowp<1, 1>(int, const DjIgemmParams&, int, hipStream_t, int, int);
