@@ -108,11 +108,21 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
   const int bc = tid % KCH, br0 = tid / KCH;
 
   int a_off[NA], a_rh[NA], a_rw[NA];
-  int r2_off[PRO == 3 ? NA : 1], y_off[PRO == 3 ? NA : 1];   // PRO 3: the same pixel in A2 / sum_out
+  // PRO 3 (1x1, stride 1, unpadded: the input pixel IS the GEMM row): only the row index is kept (-1 past M) and the three
+  // byte offsets of a row -- x, the residual operand, the stored sum -- are one 24-bit multiply-add each where they are
+  // used; with offsets and coordinates held per row and operand the 64-deep variants needed 268-323 registers (one wave
+  // per SIMD), without them 128x128 fits two
+  int pm[PRO == 3 ? NA : 1];
   int a2_c[NA], a2_dh[NA], a2_dw[NA];
   bool a2_ok[NA];
   f32x4 a2_sc[NA], a2_sh[NA];
-  if (AM != 2) {
+  if (PRO == 3) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int m = m0 + ar0 + ARPP * j;
+      pm[j] = (m < p.M) ? m : -1;
+    }
+  } else if (AM != 2) {
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       int m = m0 + ar0 + ARPP * j;
@@ -124,18 +134,10 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
         a_rh[j] = rh;
         a_rw[j] = rw;
         a_off[j] = ((img * p.srcH * p.srcW + rh * p.srcW + rw) * p.ldsrc + 4 * ac) * 4;
-        if (PRO == 3) {
-          r2_off[j] = (m * p.ldsrc2 + 4 * ac) * 4;
-          y_off[j] = (m * p.ld_sum + 4 * ac) * 4;
-        }
       } else {
         a_rh[j] = -(1 << 28);
         a_rw[j] = -(1 << 28);
         a_off[j] = 0;
-        if (PRO == 3) {
-          r2_off[j] = 0;
-          y_off[j] = 0;
-        }
       }
     }
   } else {
@@ -221,14 +223,25 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
         }
       }
       a_valid = 0;
+      if (PRO == 3) {
+        const unsigned cb = (unsigned)(4 * ac + t_c0);
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+          const bool ok = live && pm[j] >= 0;
+          const unsigned m = (unsigned)pm[j];
+          ra[j] = dj_buf_ld4(rA, ok ? (__umul24(m, (unsigned)p.ldsrc) + cb) * 4u : DJ_OOB);
+          ra2[j] = dj_buf_ld4(rA2, ok ? (__umul24(m, (unsigned)p.ldsrc2) + cb) * 4u : DJ_OOB);
+          a_valid |= ok ? (1u << j) : 0u;
+        }
+      } else {
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
         int h = (AM == 0) ? a_rh[j] + dh : a_rh[j] - dh;
         int w = (AM == 0) ? a_rw[j] + dw : a_rw[j] - dw;
         bool ok = live && (unsigned)h < (unsigned)p.srcH && (unsigned)w < (unsigned)p.srcW;
         ra[j] = dj_buf_ld4(rA, ok ? (unsigned)(a_off[j] + delta) : DJ_OOB);
-        if (PRO == 3) ra2[j] = dj_buf_ld4(rA2, ok ? (unsigned)(r2_off[j] + t_c0 * 4) : DJ_OOB);
         a_valid |= ok ? (1u << j) : 0u;
+      }
       }
     } else {
       a_valid = 0;
@@ -302,7 +315,10 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
         v.w = __builtin_amdgcn_fmed3f(v.w, lo, hi);
         if (PRO == 3 && store_sum)
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rY,
-                                                 ok ? (int)(y_off[j] + pro_c0 * 4) : (int)DJ_OOB, 0, 0);
+                                                 ok ? (int)((__umul24((unsigned)pm[j], (unsigned)p.ld_sum) +
+                                                             (unsigned)(4 * ac + pro_c0)) * 4u)
+                                                    : (int)DJ_OOB,
+                                                 0, 0);
       }
       short* dst = (AM != 2) ? sA + (ar0 + ARPP * j) * PA + 4 * ac : sA + ar0 * PA + 4 * (ac + 8 * j);
       *reinterpret_cast<dj_short4*>(dst) = dj_round4<PREC>(v);
