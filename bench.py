@@ -124,6 +124,108 @@ def cpu_baseline(archi, batch, budget_s=25.0):
                       "at batch %d; median step %.2f s" % (len(use), archi, batch, med)}
 
 
+DTYPE_NAME = {"float32": "f32", "float16": "f16/bf16-mfma+f32-acc", "bfloat16": "bf16-mfma+f32-acc"}
+
+
+def run_workload(archi, floatx, batch, steps, warmup, rank=0, world=1):
+    """Build the SSD300 training workload `archi` under arithmetic mode `floatx`, run `warmup` untimed and `steps` timed
+    training steps on a resident batch (barrier + synchronize on both sides, max over ranks) -> (elapsed seconds, last
+    loss, model, plan).  The caller's floatx is restored."""
+    from jpeg_detection_resnet_ssd_amd import dist as djdist
+    from jpeg_detection_resnet_ssd_amd import workloads
+    from jpeg_detection_resnet_ssd_amd.keras import backend as K
+    prev = K.floatx()
+    K.set_floatx(floatx)
+    try:
+        model, sizes = workloads.build_ssd(archi)
+        model._ensure_params()
+        if torch.distributed.is_initialized():
+            dp = djdist.DataParallel(model)
+            dp.broadcast_weights(0)
+        # rank r draws its own shard of the global batch (data seed 1234 + r)
+        x, y = workloads.synthetic_batch(archi, sizes, batch, seed=1234 + rank, fast=True)
+        plan = model._plan(batch, True, True)
+        model._upload(plan, x, y)
+        torch.cuda.synchronize()
+
+        def barrier():
+            if torch.distributed.is_initialized():
+                torch.distributed.barrier()
+
+        for _ in range(warmup):
+            model.run_train_step(plan)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model.run_train_step(plan)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            elapsed = float(t.item())
+        loss = model._loss_value(plan)
+        return elapsed, loss, model, plan
+    finally:
+        K.set_floatx(prev)
+
+
+def roofline_of(archi, floatx, batch, value, world, model, plan):
+    """The `roofline` object of one workload: whole-step MFMA fraction, and for world == 1 the implicit-GEMM family
+    timed launch by launch with HIP events (one extra step)."""
+    from jpeg_detection_resnet_ssd_amd import workloads
+    from jpeg_detection_resnet_ssd_amd.keras import backend as K
+    gflop = workloads.TRAIN_GFLOP_PER_IMAGE[archi]
+    per_gpu_tflops = value * gflop / 1e3 / world
+    roof = {"bound": "mfma", "achieved": per_gpu_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": per_gpu_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            "note": "whole-step algorithmic conv FLOPs (SURVEY 8(d) table) / step time, per GPU"}
+    prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    for rnd in ("r03", "r02"):
+        traffic_file = os.path.join(prof, "%s_igemm_traffic%s.json" % (rnd, "" if floatx == "float32" else "_f16"))
+        if os.path.exists(traffic_file) and archi == "deconv" and batch == 32:
+            # offline rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_f_hbm_traffic_pmc.md), bytes per launch
+            with open(traffic_file) as f:
+                roof["traffic"] = json.load(f)["bytes_per_launch"]
+            roof["traffic_source"] = os.path.basename(traffic_file) + " (separate --pmc passes of this workload, not this run)"
+            break
+    if world == 1:
+        prev = K.floatx()
+        K.set_floatx(floatx)
+        try:
+            k = measure_conv_kernels(model, plan)
+        finally:
+            K.set_floatx(prev)
+        ktf = k["flop"] / (k["total_ms"] * 1e-3) / 1e12
+        roof["dominant_kernel"] = {"name": "dj_igemm_kernel (conv fwd/dgrad/wgrad)", "launches_per_step": k["launches"],
+                                   "avg_launch_us": 1e3 * k["total_ms"] / k["launches"],
+                                   "ms_per_step": k["total_ms"], "achieved": ktf, "frac": ktf / PEAK_FP32_MFMA_TFLOPS,
+                                   "algorithmic_gflop_per_step": k["flop"] / 1e9,
+                                   "algorithmic_gbyte_per_step": k["bytes"] / 1e9,
+                                   "algorithmic_gbyte_per_s": k["bytes"] / (k["total_ms"] * 1e-3) / 1e9}
+        if floatx != "float32":
+            # reduced-precision MFMA: the GEMMs are ~16x cheaper, reading / writing the operands is what bounds the
+            # family (2.4 TF of arithmetic per GB moved at these shapes against a machine balance of 2500 TF / 8 TB/s =
+            # 312 FLOP/B): the roofline of this mode is HBM
+            gbps = k["bytes"] / (k["total_ms"] * 1e-3) / 1e9
+            roof.update({"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+                         "note": "implicit-GEMM family: algorithmic bytes (each operand read once, result written once, at "
+                                 "the width it has in HBM) / its kernel time; the arithmetic side is in `mfma`",
+                         "mfma": {"achieved": per_gpu_tflops, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": per_gpu_tflops / PEAK_F16_MFMA_TFLOPS, "kernel_family_tflops": ktf}})
+            roof["dominant_kernel"]["frac"] = gbps / PEAK_HBM_GBPS
+    return roof
+
+
+# the non-headline single-GPU configurations of BASELINE.json, measured by the same run so that the driver's record holds
+# them too (VERDICT r2 item 3): config 3 and the two workloads of config 5
+SECONDARY = [("ssd_custom", "float32"), ("deconv", "float16"), ("ssd_custom", "float16"), ("up_sampling", "float16")]
+
+
 def main(json_out=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,56 +235,23 @@ def main(json_out=None):
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (the reference trainer's batch_size)")
     ap.add_argument("--floatx", default="float32", choices=["float32", "float16", "bfloat16"],
                     help="conv arithmetic: float32 = exact fp32 MFMA (the headline); float16 / bfloat16 = BASELINE config 5's "
-                         "reduced-precision MFMA with fp32 master tensors and accumulation (reported with its own dtype)")
+                         "reduced-precision MFMA with fp32 master weights and accumulation (reported with its own dtype)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` list (config 3 / config 5 workloads)")
     ap.add_argument("--cpu-batch", type=int, default=8, help="batch of the CPU-oracle sample (BASELINE.md: 8)")
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of CPU work for the cpu_baseline sample")
     args = ap.parse_args()
 
     from jpeg_detection_resnet_ssd_amd import dist as djdist
     from jpeg_detection_resnet_ssd_amd import workloads
-    rank, world, local = djdist.init_from_env()
+    rank, world, local = djdist.init_from_env()      # ranks are initialised before any GPU call
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the compute path has no CPU fallback")
     torch.cuda.set_device(local)
 
-    from jpeg_detection_resnet_ssd_amd.keras import backend as K
-    K.set_floatx(args.floatx)
-    model, sizes = workloads.build_ssd(args.archi)
-    model._ensure_params()
-    dp = None
-    if torch.distributed.is_initialized():
-        dp = djdist.DataParallel(model)
-        dp.broadcast_weights(0)
-    # rank r draws its own shard of the global batch (data seed 1234 + r)
-    x, y = workloads.synthetic_batch(args.archi, sizes, args.batch, seed=1234 + rank, fast=True)
-    plan = model._plan(args.batch, True, True)
-    model._upload(plan, x, y)
-    torch.cuda.synchronize()
-
-    def barrier():
-        if torch.distributed.is_initialized():
-            torch.distributed.barrier()
-
-    for _ in range(args.warmup):
-        model.run_train_step(plan)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        model.run_train_step(plan)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-    loss = model._loss_value(plan)
+    elapsed, loss, model, plan = run_workload(args.archi, args.floatx, args.batch, args.steps, args.warmup, rank, world)
     print("rank %d: %d steps in %.3f s, last loss %.4f" % (rank, args.steps, elapsed, loss), file=sys.stderr, flush=True)
 
     if rank != 0:
@@ -190,12 +259,11 @@ def main(json_out=None):
     images = world * args.batch * args.steps
     value = images / elapsed
     gflop = workloads.TRAIN_GFLOP_PER_IMAGE[args.archi]
-    per_gpu_tflops = value * gflop / 1e3 / world
     out = {
         "metric": "images/sec (train) ResNet50-DCT-SSD300",
         "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": {"float32": "f32", "float16": "f16/bf16-mfma+f32-acc", "bfloat16": "bf16-mfma+f32-acc"}[args.floatx],
+        "vs_baseline": None, "dtype": DTYPE_NAME[args.floatx],
         "data": "synthetic",
         "config": {"workload": "SSD300 ResNet50-DCT '%s' archi, %d images/GPU, 300x300 JPEG-DCT inputs "
                                "(Y 38x38x64 + chroma 19x19), fwd+loss+bwd+SGD(+RCCL all-reduce); batch and encoded targets "
@@ -208,38 +276,25 @@ def main(json_out=None):
                                 "1 GPU; the RCCL exchange has only ever run on a 1-rank communicator (no multi-GPU box "
                                 "was available to the builder): no scaling curve has been measured"},
     }
-    roof = {"bound": "mfma", "achieved": per_gpu_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": per_gpu_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-            "note": "whole-step algorithmic conv FLOPs (SURVEY 8(d) table) / step time, per GPU"}
-    prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    traffic_file = os.path.join(prof, "r02_igemm_traffic.json" if args.floatx == "float32" else "r02_igemm_traffic_f16.json")
-    if not os.path.exists(traffic_file) and args.floatx == "float32":
-        traffic_file = os.path.join(prof, "r01_igemm_traffic.json")
-    if os.path.exists(traffic_file) and args.archi == "deconv" and args.batch == 32:
-        # offline rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_f_hbm_traffic_pmc.md), bytes per launch
-        with open(traffic_file) as f:
-            roof["traffic"] = json.load(f)["bytes_per_launch"]
-    if world == 1:
-        k = measure_conv_kernels(model, plan)
-        ktf = k["flop"] / (k["total_ms"] * 1e-3) / 1e12
-        roof["dominant_kernel"] = {"name": "dj_igemm_kernel (conv fwd/dgrad/wgrad)", "launches_per_step": k["launches"],
-                                   "avg_launch_us": 1e3 * k["total_ms"] / k["launches"],
-                                   "ms_per_step": k["total_ms"], "achieved": ktf, "frac": ktf / PEAK_FP32_MFMA_TFLOPS,
-                                   "algorithmic_gflop_per_step": k["flop"] / 1e9,
-                                   "algorithmic_gbyte_per_step": k["bytes"] / 1e9,
-                                   "algorithmic_gbyte_per_s": k["bytes"] / (k["total_ms"] * 1e-3) / 1e9}
-        if args.floatx != "float32":
-            # reduced-precision MFMA over fp32 tensors: the GEMMs are ~16x cheaper, reading / writing the fp32 operands
-            # is what bounds the family (2.4 TF of arithmetic per GB moved at these shapes against a machine balance of
-            # 2500 TF / 8 TB/s = 312 FLOP/B): the roofline of this mode is HBM
-            gbps = k["bytes"] / (k["total_ms"] * 1e-3) / 1e9
-            roof.update({"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
-                         "note": "implicit-GEMM family: algorithmic bytes (each fp32 operand read once, result written once) "
-                                 "/ its kernel time; the arithmetic side is in `mfma`",
-                         "mfma": {"achieved": per_gpu_tflops, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": per_gpu_tflops / PEAK_F16_MFMA_TFLOPS, "kernel_family_tflops": ktf}})
-            roof["dominant_kernel"]["frac"] = gbps / PEAK_HBM_GBPS
-    out["roofline"] = roof
+    out["roofline"] = roofline_of(args.archi, args.floatx, args.batch, value, world, model, plan)
+    del model, plan
+    torch.cuda.empty_cache()
+    if world == 1 and not args.no_secondary and (args.archi, args.floatx, args.batch) == ("deconv", "float32", 32):
+        sec = []
+        for archi, floatx in SECONDARY:
+            steps = min(args.steps, 20)
+            el, ls, m2, p2 = run_workload(archi, floatx, args.batch, steps, min(args.warmup, 3))
+            v = args.batch * steps / el
+            sec.append({"config": {"workload": "SSD300 ResNet50-DCT '%s' archi, %d images/GPU" % (archi, args.batch),
+                                   "archi": archi, "train_gflop_per_image": workloads.TRAIN_GFLOP_PER_IMAGE[archi],
+                                   "last_loss": ls},
+                        "value": v, "unit": "images/sec", "ms_per_step": 1e3 * el / steps, "steps": steps,
+                        "dtype": DTYPE_NAME[floatx], "roofline": roofline_of(archi, floatx, args.batch, v, 1, m2, p2)})
+            print("secondary %s %s: %.1f img/s (%.2f ms/step)" % (archi, floatx, v, 1e3 * el / steps), file=sys.stderr,
+                  flush=True)
+            del m2, p2
+            torch.cuda.empty_cache()
+        out["secondary"] = sec
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.archi, args.cpu_batch, args.cpu_budget)
     print(json.dumps(out), file=json_out or sys.stdout, flush=True)

@@ -34,6 +34,11 @@ extern "C" {
 #endif
 
 const char* dj_last_error(void);
+/* Version of this interface: bumped whenever an entry point is added or the meaning of an argument changes
+ * (2: the `beta` / `relu` bit fields, the workspace and BatchNormalization-backward-statistics entry points, the per-thread
+ * arithmetic mode; 3: the dtype-carrying `_t` entry points for 16-bit tensors in HBM, the tuner direction 9).  A binding
+ * written for one version must refuse a library that reports another (jpeg_detection_resnet_ssd_amd/_lib.py does). */
+#define DJ_ABI_VERSION 3
 int dj_abi_version(void);
 
 /* Geometry of one keras.layers.Conv2D (third-party; used at
@@ -168,7 +173,9 @@ int dj_set_thread_compute_mode(int mode);
 int dj_get_compute_mode(void);
 
 /* Launch-configuration overrides per conv geometry, filled by the plan-time autotuner: `dir` 0 fwd, 1 dgrad,
- * 2 wgrad (+4: forward that takes BN statistics); cfg in [0, dj_conv2d_tune_configs()) selects the tile shape
+ * 2 wgrad (+4: forward that takes BN statistics; 9: the input gradient of dj_conv2d_nhwc_dgrad_bnbwd, which runs other
+ * kernels than a plain input gradient and is never split -- without an entry of its own it takes the tile shape of the
+ * dir-1 entry); cfg in [0, dj_conv2d_tune_configs()) selects the tile shape
  * (128x128, 128x64, 64x64, 128x32), `splits` the split-K factor; cfg < 0 removes the override. */
 int dj_conv2d_tune_configs(void);
 int dj_conv2d_tune_set(int dir, const dj_conv2d_desc* d, int cfg, int splits);

@@ -38,6 +38,7 @@ class ConvDesc(Structure):
 
 
 _lib = None
+ABI_VERSION = 3     # DJ_ABI_VERSION of include/dj_hip.h these bindings were written for
 
 
 def load():
@@ -54,6 +55,13 @@ def load():
     # launched on the device the other one owns ("no ROCm-capable device is detected")
     import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
+    lib.dj_abi_version.restype = c_int
+    have = lib.dj_abi_version()
+    if have != ABI_VERSION:
+        # a stale build product (the .so is git-ignored and travels with the working tree): calling it through these
+        # signatures would pass arguments it reads differently
+        raise DjError("%s reports ABI version %d, these bindings are written for %d: rebuild it "
+                      "(`python -c 'import __graft_entry__ as g; g.build()'`)" % (LIB_PATH, have, ABI_VERSION))
     _declare(lib)
     _lib = lib
     return lib

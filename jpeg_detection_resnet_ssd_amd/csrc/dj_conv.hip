@@ -16,7 +16,7 @@ void dj_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* dj_last_error(void) { return g_err; }
-extern "C" int dj_abi_version(void) { return 1; }
+extern "C" int dj_abi_version(void) { return DJ_ABI_VERSION; }
 
 // ---- the library's only mutable state: three settings, each safe to touch from any thread ----
 // test switch: atomic, read once per launch
@@ -119,7 +119,8 @@ static bool tune_lookup(int dir, const dj_conv2d_desc* d, int* cfg, int* splits)
 
 extern "C" int dj_conv2d_tune_configs(void) { return N_CFG; }
 
-// dir: 0 fwd, 1 dgrad, 2 wgrad, +4 when the forward takes BN statistics.  cfg < 0 removes the override.
+// dir: 0 fwd, 1 dgrad, 2 wgrad, +4 when the forward takes BN statistics, 9 = input gradient that takes the
+// BatchNormalization backward statistics (dj_conv2d_nhwc_dgrad_bnbwd).  cfg < 0 removes the override.
 extern "C" int dj_conv2d_tune_set(int dir, const dj_conv2d_desc* d, int cfg, int splits) {
   DJ_CHECK_ARG(d != nullptr && cfg < N_CFG && splits >= 1, "tune_set: bad arguments");
   std::lock_guard<std::mutex> g(g_tune_mu);
@@ -620,7 +621,9 @@ static int conv_dgrad_impl(const dj_conv2d_desc* d, const float* dy, const float
   fill_geom(p, d);
   p.cmap = 0;
   int cfg = choose_cfg(p.M, p.N, p.K, true, &splits);
-  tune_lookup(1, d, &cfg, &splits);
+  // the launch that also takes BatchNormalization backward statistics runs the EPI twin and is never split: a tuner
+  // entry of its own (direction 9), falling back to the plain input gradient's tile variant
+  if (!(bnb && tune_lookup(9, d, &cfg, &splits))) tune_lookup(1, d, &cfg, &splits);
   if (one_k_range) splits = 1;
   p.kchunk = dj_cdiv(dj_cdiv(p.K, splits), DJ_BK) * DJ_BK;
   splits = dj_cdiv(p.K, p.kchunk);

@@ -5,6 +5,7 @@
 #include "dj_igemm.h"
 #include "dj_igemm_fast.h"
 #include <stdlib.h>
+#include <atomic>
 
 // ---------------------------------------------------------------------------------
 // tile configurations
@@ -35,14 +36,16 @@ enum {
 
 template <typename KernT>
 static int launch_kernel(KernT kern, int smem_bytes, int bm, int bn, const DjIgemmParams& p, int splits, hipStream_t s,
-                         bool* attr_done, int threads = 256) {
-  if (!*attr_done) {
+                         std::atomic<bool>* attr_done, int threads = 256) {
+  // (first launch of an instantiation: two threads may both get here -- the call is idempotent, the flag is atomic so
+  // that the header's "callable from any thread" holds by the letter as well)
+  if (!attr_done->load(std::memory_order_relaxed)) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     if (e != hipSuccess) {
       dj_set_error("hipFuncSetAttribute(%d B LDS): %s", smem_bytes, hipGetErrorString(e));
       return DJ_ERR_HIP;
     }
-    *attr_done = true;
+    attr_done->store(true, std::memory_order_relaxed);
   }
   int tiles_m = dj_cdiv(p.M, bm), tiles_n = dj_cdiv(p.N, bn);
   dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)splits);
@@ -57,12 +60,12 @@ template <int BM, int BN, int WM, int WN, int AM, int BMD, int PRO, int NSTAGE, 
 static int launch_fast(int smem_bytes, const DjIgemmParams& p, int splits, hipStream_t s, int threads = 256) {
   if constexpr (AM == 1 && BMD == 1 && PRO == 0) {   // (the input-gradient GEMM has no prologue)
     if (p.bnb_z) {
-      static bool done1 = false;
+      static std::atomic<bool> done1{false};
       return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, PRO, NSTAGE, PREC, KS, NP, 1>, smem_bytes, BM, BN, p,
                            splits, s, &done1, threads);
     }
   }
-  static bool done0 = false;
+  static std::atomic<bool> done0{false};
   return launch_kernel(dj_igemm_fast_kernel<BM, BN, WM, WN, AM, BMD, PRO, NSTAGE, PREC, KS, NP, 0>, smem_bytes, BM, BN, p, splits,
                        s, &done0, threads);
 }
@@ -71,7 +74,7 @@ static int launch_fast(int smem_bytes, const DjIgemmParams& p, int splits, hipSt
 template <int BM, int BN, int WM, int WN, int AM, int BMD, int NSTAGE>
 static int launch_one(const DjIgemmParams& p, int splits, hipStream_t s, int fast) {
   using Cfg = DjIgemmCfg<BM, BN, WM, WN, AM, BMD>;
-  static bool done[1] = {false};
+  static std::atomic<bool> done[1] = {{false}};
   const int smem_fast = Cfg::SMEM_BYTES / 2 * ((NSTAGE == 2 || NSTAGE == 4) ? 2 : 1);
   {
     // 1x1 kernels without padding: the variant that does no per-K-step bounds arithmetic (NP, see dj_igemm_fast.h); for
@@ -134,7 +137,6 @@ static int launch_k2(const DjIgemmParams& p, int splits, hipStream_t s, int fast
   return launch_fast<BM, BN, 2, 2, AM, BMD, 1, 4, 0, 2, 0>(2 * Cfg::SMEM_BYTES, p, splits, s, 512);
 }
 
-#include <atomic>
 extern std::atomic<bool> g_dj_allow_fast;   // dj_conv.hip
 
 // 0: fp32 MFMA everywhere (default).  1: forward GEMMs round their operands to fp16, gradient GEMMs (dgrad, wgrad) to

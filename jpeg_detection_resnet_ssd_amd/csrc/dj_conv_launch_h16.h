@@ -9,12 +9,12 @@ template <int BM, int BN, int AM, int BMD, int PRO, int PREC, int BK, int PF>
 static int launch_h16_kernel(int smem_bytes, const DjIgemmParams& p, int splits, hipStream_t s) {
   if constexpr (AM == 1 && BMD == 1 && PRO == 0) {
     if (p.bnb_z) {
-      static bool done1 = false;
+      static std::atomic<bool> done1{false};
       return launch_kernel(dj_igemm_h16_kernel<BM, BN, AM, BMD, PRO, PREC, BK, PF, 1>, smem_bytes, BM, BN, p, splits, s, &done1,
                            256);
     }
   }
-  static bool done0 = false;
+  static std::atomic<bool> done0{false};
   return launch_kernel(dj_igemm_h16_kernel<BM, BN, AM, BMD, PRO, PREC, BK, PF, 0>, smem_bytes, BM, BN, p, splits, s, &done0, 256);
 }
 

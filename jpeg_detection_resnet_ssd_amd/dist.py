@@ -102,7 +102,6 @@ class DataParallel(object):
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         model.dist = self
         self.exchange = None
-        self._attached = set()
         # training plans lowered BEFORE the model became data parallel (train_on_batch, or the trainer's warm-up, called
         # first) have no all-reduce in their launch lists: splice it in now, or the replicas would silently diverge
         for key, plan in list(model._plans.items()):
@@ -116,7 +115,10 @@ class DataParallel(object):
 
     def attach(self, plan):
         """Insert the bucketed all-reduces into the plan's backward launch list."""
-        if not dist.is_initialized() or id(plan) in self._attached:
+        # the plan itself carries the mark (an id() in a set could be reused by a plan lowered after this one was freed:
+        # Model.compile drops its plans -- the early-out below and the guard of finish_gradients would then both pass
+        # for a plan without an exchange)
+        if not dist.is_initialized() or getattr(plan, "_dp_attached", None) is self:
             return
         m = self.model
         if self.exchange is None:
@@ -134,14 +136,14 @@ class DataParallel(object):
             # for the main stream's bias / BatchNormalization gradients) while the main stream runs on -- a join here
             # would stall the data-gradient chain once per bucket (27.54 vs 27.89 ms/step on a 1-rank communicator)
             plan.bwd.insert(idx, (lambda r=ranges: plan.after_both_streams(lambda: ex.launch(r))))
-        self._attached.add(id(plan))
+        plan._dp_attached = self
         self.n_buckets = len(buckets)
 
     def finish_gradients(self, plan=None):
         """Wait for the step's all-reduces; -> the factor (1/world) the optimizer applies to the summed gradients."""
         if not dist.is_initialized():
             return 1.0
-        if plan is not None and id(plan) not in self._attached:
+        if plan is not None and getattr(plan, "_dp_attached", None) is not self:
             raise RuntimeError("data parallel: the training plan that just ran has no gradient exchange attached "
                                "(its gradients are per-rank): replicas would diverge")
         if self.exchange is None:

@@ -34,6 +34,13 @@ def _side_stream(device):
     return _SIDE[key]
 
 
+class _DrySideStream(object):
+    """Stands in for the side stream of a plan lowered on the host: nothing can be enqueued on it."""
+
+    def __getattr__(self, name):
+        raise RuntimeError("this plan was lowered on the CPU for structure checks only: it cannot run")
+
+
 def _conv(a):
     if isinstance(a, torch.Tensor):
         return a.data_ptr()
@@ -88,10 +95,22 @@ def colsum_multi(parts):
     return run
 
 
+def _db_lookup(key):
+    """Table entry of a tuner key (direction, geometry...).  Direction 9 -- the input gradient that also takes the
+    BatchNormalization backward statistics, never split -- falls back to the plain input gradient's tile variant."""
+    db = _tune_db()
+    known = db.get(",".join(str(int(v)) for v in key))
+    if known is None and key[0] == 9:
+        plain = db.get(",".join(str(int(v)) for v in (1,) + tuple(key[1:])))
+        if plain is not None:
+            known = [plain[0], 1, plain[2]]
+    return known
+
+
 def tuned_splits(direction, desc):
     """Split-K factor the in-tree table registers for this geometry (None: not in the table)."""
     names = [n for n, _ in _lib.ConvDesc._fields_][:15]
-    known = _tune_db().get(",".join(str(int(v)) for v in ((direction,) + tuple(getattr(desc, n) for n in names))))
+    known = _db_lookup((direction,) + tuple(getattr(desc, n) for n in names))
     return None if known is None else int(known[1])
 
 
@@ -250,9 +269,29 @@ class _Workspace(object):
         if need > self.buf.numel():
             self.buf = torch.empty(need, dtype=torch.float32, device=self.device)
 
+    def fit_splits(self, splits):
+        """Room for every registered geometry at split-K factor `splits` (the tuner's trial launches must run the slab
+        path they are being timed for, not the atomics fallback of a workspace that is too small); geometries whose
+        slabs would exceed the cap are left to `splits_fit`."""
+        if self.off:
+            return
+        need = 4
+        for desc, _ in self.users:
+            n = int(splits) * desc.batch * desc.out_h * desc.out_w * desc.out_c
+            if n <= self.CAP_FLOATS:
+                need = max(need, n)
+        if need > self.buf.numel():
+            self.buf = torch.empty(need, dtype=torch.float32, device=self.device)
+
     def resize(self):
+        """Size for the CURRENT tuning choice of every registered geometry (shrinks after a tuning pass)."""
+        if self.off:
+            return
+        need = 4
         for desc, may in self.users:
-            self._fit(desc, may)
+            need = max(need, min(int(query_long("dj_conv2d_fwd_workspace_floats", desc, int(may))), self.CAP_FLOATS))
+        if need != self.buf.numel():
+            self.buf = torch.empty(need, dtype=torch.float32, device=self.device)
 
 
 class Plan(object):
@@ -290,6 +329,12 @@ class Plan(object):
         if training and device.type == "cuda" and os.environ.get("DJ_SIDE_WGRAD", "1") != "0":
             self.side_stream = _side_stream(device)
             self._join_event = torch.cuda.Event()
+        elif training and device.type != "cuda" and os.environ.get("DJ_SIDE_WGRAD", "1") != "0":
+            # structure-only lowering on the host (tests/test_dist_gloo.py walks launch lists, gradient-ready indices and
+            # buckets without a GPU): the same lists as on the card -- side-stream heads, fused launches -- whose closures
+            # are never run; Model._ensure_params only accepts a CPU device when it is asked for explicitly
+            self.side_stream = _DrySideStream()
+            self._join_event = None
 
     # ---- allocation -------------------------------------------------------------
     def empty(self, *shape):
@@ -403,7 +448,8 @@ class Plan(object):
             self.fwd.append(wait)
 
     def emit_conv(self, direction, desc, fn, backward=False, side=False, fwd_after=None):
-        """Record one implicit-GEMM launch (direction 0 fwd / 1 dgrad / 2 wgrad, +4 = forward with BN statistics).
+        """Record one implicit-GEMM launch (direction 0 fwd / 1 dgrad / 2 wgrad, +4 = forward with BN statistics, 9 =
+        input gradient that takes BatchNormalization backward statistics: the tuner keys of include/dj_hip.h).
         side=True: the launch has no consumer before the optimizer / gradient exchange and every buffer it reads is
         final when it is issued, so it may run on the plan's side stream."""
         self.conv_calls.append((direction, desc, fn))
@@ -455,11 +501,12 @@ class Plan(object):
         ncfg = lib.dj_conv2d_tune_configs()
         names = [n for n, _ in _lib.ConvDesc._fields_][:15]
         done = 0
+        grown = False
         for direction, desc, fn in self.conv_calls:
             key = (direction,) + tuple(getattr(desc, n) for n in names)
             if key in _TUNED:
                 continue
-            known = _tune_db().get(",".join(str(int(v)) for v in key))
+            known = _db_lookup(key)
             if known is not None and known[0] < ncfg:
                 sp = int(known[1])
                 if len(known) > 3 and known[3]:
@@ -477,13 +524,26 @@ class Plan(object):
             c0, s0 = ctypes.c_int(0), ctypes.c_int(1)
             check(lib.dj_conv2d_default_config(direction, desc, ctypes.byref(c0), ctypes.byref(s0)), "default_config")
             base = direction & 3
-            if direction & 4 or getattr(fn, "no_split", False):
+            if direction & 4 or direction == 9 or getattr(fn, "no_split", False):
                 split_opts = [1]
             elif base == 2:
                 kk = desc.batch * desc.out_h * desc.out_w
                 split_opts = sorted({1, max(1, s0.value // 2), s0.value, min(max(1, kk // 128), s0.value * 2)})
             else:
                 split_opts = sorted({1, s0.value, 2, 4})
+            if base == 0 and not (direction & 4):
+                # a split forward launch goes through slabs in the plan's workspace (sized so far for the pre-tuning
+                # choice): make room for the largest factor tried, and do not time a factor whose slabs exceed the cap --
+                # it would run the atomics fallback, not what the plan runs afterwards
+                mn = desc.batch * desc.out_h * desc.out_w * desc.out_c
+                split_opts = [sp for sp in split_opts if sp == 1 or sp * mn <= _Workspace.CAP_FLOATS]
+                if not grown:
+                    for ws in self._workspaces.values():
+                        ws.fit_splits(max(8, s0.value))
+                    grown = True
+                if max(split_opts) > 8:
+                    for ws in self._workspaces.values():
+                        ws.fit_splits(max(split_opts))
             best = (float("inf"), c0.value, s0.value)
             for cfg in range(ncfg):
                 for sp in split_opts:

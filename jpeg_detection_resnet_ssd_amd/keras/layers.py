@@ -512,7 +512,7 @@ class Conv2D(Layer):
                     def fused_dgrad():
                         return Kn.conv2d_dgrad_bnbwd(desc, dy, wgt, dx, zbuf, mean, invstd, msc, msh, part)
                     fused_dgrad.no_split = True      # for the tuners: a registered split-K factor is ignored here
-                    plan.emit_conv(1, desc, fused_dgrad, backward=True)
+                    plan.emit_conv(9, desc, fused_dgrad, backward=True)   # tuned and recorded apart from plain dgrads
                     x.grad.bwd_partial = (part, nr)
                 else:
                     dx, beta = plan.grad_of(x, zeroed=own_memset and os.environ.get("DJ_ZERO_ARENA", "1") != "0")
@@ -951,8 +951,10 @@ class Concatenate(Layer):
                 src, lds, rws = t, n, outer
             dst = yflat[:, off:off + n]
             if getattr(v_of[id(t)], "constant", False):
-                # constant input (the anchor boxes): its slice of y is written once, now
-                call("dj_copy2d", src, lds, dst, total, rws, n, 0)
+                # constant input (the anchor boxes): its slice of y is written once, now (not in a structure-only
+                # lowering on the host, which launches nothing)
+                if plan.device.type == "cuda":
+                    call("dj_copy2d", src, lds, dst, total, rws, n, 0)
             else:
                 live_parts.append((src, lds, dst, total, rws, n, 0))
         if len(live_parts) == 1:

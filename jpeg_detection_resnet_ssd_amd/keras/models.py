@@ -417,12 +417,14 @@ class Model(object):
                                  % (tuple(plan.y_true.shape), tuple(t.shape)))
             plan.y_true.copy_(t.to(torch.float32), non_blocking=True)
 
-    def _apply_optimizer(self):
+    def _apply_optimizer(self, plan=None):
+        """`plan`: the training plan whose backward pass just ran (data parallel: it must carry the gradient exchange;
+        None = the plan of the last run_train_step)."""
         st, opt = self._store, self.optimizer
         lr_t = opt.current_lr()
         scale = 1.0
         if self.dist is not None:
-            scale = self.dist.finish_gradients(self._last_train_plan)
+            scale = self.dist.finish_gradients(plan if plan is not None else self._last_train_plan)
         st["sumsq"].zero_()
         for i, (a, b, l2) in enumerate(st["segments"]):
             if b <= a:
@@ -437,7 +439,7 @@ class Model(object):
         self._last_train_plan = plan
         plan.run_forward()
         plan.run_backward()
-        self._apply_optimizer()
+        self._apply_optimizer(plan)
 
     def _loss_value(self, plan, with_reg=True):
         vals = plan.loss_out.detach().cpu()

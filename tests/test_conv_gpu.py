@@ -162,9 +162,9 @@ VARIANT_CASES = [
     (3, 19, 19, 96, 128, 3, 1, "same", 1),      # K = 27 K-steps (odd: the K groups of the *_PK2 variants get 14 / 13)
     (2, 10, 10, 64, 192, 1, 1, "valid", 1),     # K = 2 K-steps, N = 1.5 tiles of 128
     (2, 38, 38, 32, 64, 2, 1, "same", 1),       # one K-step per tap (srcC = 32), asymmetric padding
-    (3, 19, 19, 128, 96, 3, 1, "same", 1),      # LDS-free wgrad, scalar-addressed form: one tap per wave tile, odd pixel count
+    (3, 19, 19, 128, 96, 3, 1, "same", 1),      # pixel-walk wgrad, one tap per 128-row tile, odd pixel count (1083)
     (3, 19, 19, 256, 40, 3, 1, "same", 2),      # ... dilation 2, N not a multiple of 32
-    (5, 7, 9, 128, 64, 1, 1, "valid", 1),       # ... 1x1 (no padding tests), 315 pixels
+    (5, 7, 9, 128, 64, 1, 1, "valid", 1),       # 1x1 unpadded (the NP kernels: no bounds arithmetic), 315 pixels
     (2, 11, 13, 128, 64, 3, 2, "same", 1),      # pixel-walk wgrad (in_c % BM == 0): stride 2, output grid != input grid
     (7, 3, 3, 128, 64, 3, 1, "same", 1),        # ... a map smaller than a K-step (9 pixels): image carries every step
     (3, 9, 5, 256, 32, 3, 2, "valid", 1),       # ... stride 2 without padding, 4x2 outputs per image

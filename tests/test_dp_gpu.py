@@ -1,4 +1,5 @@
-"""GPU (one card, two processes, gloo transport): the data-parallel training step end to end --
+"""GPU (two processes: over RCCL with one card each when the box has two, else both on one card over gloo): the
+data-parallel training step end to end --
 bucketed all-reduces inserted into the backward launch list, 1/world in the SGD kernel, weight broadcast.
 Checks: (a) bit-identical trainable weights on every rank after each step, (b) the 2-rank
 result equals a single-process emulation that averages the two per-shard gradients."""
@@ -23,10 +24,14 @@ def _free_port():
 
 
 def _rank_main(rank, world, port, out):
-    # DJ_TEST_DP_BACKEND=nccl with DJ_TEST_DP_GPUS >= world runs the same checks over RCCL, one GPU per rank (a lease
-    # with two or more cards); the default is what a one-GPU box can do: both ranks on card 0, gloo transport
-    backend = os.environ.get("DJ_TEST_DP_BACKEND", "gloo")
-    local = rank if int(os.environ.get("DJ_TEST_DP_GPUS", "1")) >= world else 0
+    # On a box with at least `world` cards the checks run over RCCL, one GPU per rank, without anybody setting anything
+    # (a driver run on a multi-GPU box must not silently fall back); on a one-GPU box both ranks
+    # share card 0 and the transport is gloo.  DJ_TEST_DP_BACKEND / DJ_TEST_DP_GPUS override the detection.
+    import torch
+    n_gpus = int(os.environ.get("DJ_TEST_DP_GPUS", str(torch.cuda.device_count())))
+    one_each = n_gpus >= world
+    backend = os.environ.get("DJ_TEST_DP_BACKEND", "nccl" if one_each else "gloo")
+    local = rank if one_each else 0
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(local))
     import torch
@@ -45,7 +50,7 @@ def _rank_main(rank, world, port, out):
         losses.append(model.train_on_batch(x, y))
     torch.cuda.synchronize()
     out.put((rank, model.flat_trainable.detach().cpu().numpy(), losses, dp.n_buckets,
-             None if w_init is None else w_init.numpy()))
+             None if w_init is None else w_init.numpy(), backend, local))
     torch.distributed.destroy_process_group()
 
 
@@ -63,7 +68,10 @@ def test_two_rank_step_matches_gradient_averaging(cuda, monkeypatch):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    (_, w0, l0, nb, w_init), (_, w1, l1, _, _) = res
+    (_, w0, l0, nb, w_init, backend, _), (_, w1, l1, _, _, _, local1) = res
+    print("two-rank step over %s, rank 1 on card %d" % (backend, local1))
+    if torch.cuda.device_count() >= 2 and "DJ_TEST_DP_BACKEND" not in os.environ and "DJ_TEST_DP_GPUS" not in os.environ:
+        assert backend == "nccl" and local1 == 1
     assert nb >= 2
     np.testing.assert_array_equal(w0, w1)            # (a) replicas stay bit-identical
 
@@ -131,7 +139,7 @@ def _one_rank_rccl_main(port, out):
     assert torch.distributed.get_backend() == "nccl" and (rank, world) == (0, 1)
     dp = dj.DataParallel(model, bucket_mb=16)  # AFTER the plan was cached: the constructor must splice the exchange in
     plan = model._plan(BATCH, True, True)
-    assert id(plan) in dp._attached
+    assert plan._dp_attached is dp
     dp.broadcast_weights(0)
     launched = []
     orig = dp.exchange.launch

@@ -33,8 +33,11 @@ ARCHI, BATCH = "deconv", 32
 TOL = 1e-3
 
 
+_DT = [torch.float64]     # dtype of the oracle's arithmetic (Replay sets it: fp64, fp32 in the reduced-precision cases)
+
+
 def _f64(t):
-    return None if t is None else t.detach().to("cpu", torch.float64)
+    return None if t is None else t.detach().to("cpu", _DT[0])
 
 
 def _pad_for(desc):
@@ -66,8 +69,12 @@ def _rel_max(got, ref):
 class Replay(object):
     """Wraps the kernels.conv2d_* wrappers and the BatchNormalization launches of `engine.call`."""
 
-    def __init__(self):
+    def __init__(self, lowp=False):
+        # lowp: a reduced-precision mode -- the oracle runs in fp32 there (the bounds are 1.5e-3 and up; fp64 would only
+        # double the CPU time), in fp64 for the exact-fp32 mode
+        self.dt = _DT[0] = torch.float32 if lowp else torch.float64
         self.seen = set()
+        self.new = set()        # the launches THIS recorder checked (self.seen may be shared across test cases)
         self.rows = []          # (kind, geometry, metric name, value)
         self.cpu_s = 0.0
         self.bn_fin = {}        # id(k0 tensor) -> args of the dj_bn_bwd_finalize that produced k0 / k1 / k2
@@ -90,6 +97,7 @@ class Replay(object):
             if key in self.seen:
                 return orig(desc, x, w, bias, y, pro_scale, pro_shift, pro_relu, relu, stats, y_zeroed, **kw)
             self.seen.add(key)
+            self.new.add(key)
             before = y.clone() if y_zeroed else None
             orig(desc, x, w, bias, y, pro_scale, pro_shift, pro_relu, relu, stats, y_zeroed, **kw)
             torch.cuda.synchronize()
@@ -105,7 +113,7 @@ class Replay(object):
                 ref = ko.relu(ref)
             if before is not None:
                 assert float(before.abs().max()) == 0.0, "split-K forward output was not cleared"
-            m = dict(y_max=_rel_max(_f64(y), ref))
+            m = dict(y_max=_rel_max(_f64(y), ref), y_l2=_rel_l2(_f64(y), ref))
             if stats is not None:
                 st = _f64(stats).sum(dim=0)
                 s_ref, q_ref = raw.sum(dim=(0, 1, 2)), (raw * raw).sum(dim=(0, 1, 2))
@@ -125,6 +133,7 @@ class Replay(object):
             if key in self.seen:
                 return orig(desc, x, w, bias, y, pro_scale, pro_shift, res, res_scale, res_shift, sum_out, relu, stats, **kw)
             self.seen.add(key)
+            self.new.add(key)
             orig(desc, x, w, bias, y, pro_scale, pro_shift, res, res_scale, res_shift, sum_out, relu, stats, **kw)
             torch.cuda.synchronize()
             t0 = time.time()
@@ -136,7 +145,7 @@ class Replay(object):
             ref = raw + _f64(bias) if bias is not None else raw
             if relu:
                 ref = ko.relu(ref)
-            m = dict(y_max=_rel_max(_f64(y), ref))
+            m = dict(y_max=_rel_max(_f64(y), ref), y_l2=_rel_l2(_f64(y), ref))
             if sum_out is not None:
                 m["sum_max"] = _rel_max(_f64(sum_out), a)
             if stats is not None:
@@ -155,11 +164,12 @@ class Replay(object):
             if key in self.seen:
                 return orig(desc, dy, w, dx, bias, beta, **kw)
             self.seen.add(key)
+            self.new.add(key)
             before = dx.clone() if beta else None
             orig(desc, dy, w, dx, bias, beta, **kw)
             torch.cuda.synchronize()
             t0 = time.time()
-            x0 = torch.zeros(tuple(dx.shape), dtype=torch.float64, requires_grad=True)
+            x0 = torch.zeros(tuple(dx.shape), dtype=_DT[0], requires_grad=True)
             _oracle_conv(x0, _f64(w), None, desc).backward(_f64(dy))
             ref = x0.grad
             if bias is not None:          # Conv2DTranspose forward: + bias[channel of dx]
@@ -178,15 +188,16 @@ class Replay(object):
             if key in self.seen:
                 return orig(desc, dy, w, dx, z, mean, invstd, scale, shift, partial)
             self.seen.add(key)
+            self.new.add(key)
             orig(desc, dy, w, dx, z, mean, invstd, scale, shift, partial)
             torch.cuda.synchronize()
             t0 = time.time()
-            x0 = torch.zeros(tuple(dx.shape), dtype=torch.float64, requires_grad=True)
+            x0 = torch.zeros(tuple(dx.shape), dtype=_DT[0], requires_grad=True)
             _oracle_conv(x0, _f64(w), None, desc).backward(_f64(dy))
             c = dx.shape[-1]
             g, zz = _f64(dx).reshape(-1, c), _f64(z).reshape(-1, c)
             if scale is not None:
-                g = g * ((zz * _f64(scale) + _f64(shift)) > 0).to(torch.float64)
+                g = g * ((zz * _f64(scale) + _f64(shift)) > 0).to(_DT[0])
             want0, want1 = g.sum(0), (g * (zz - _f64(mean)) * _f64(invstd)).sum(0)
             got = _f64(partial).sum(0)
             n_rows = float(g.shape[0])
@@ -204,6 +215,7 @@ class Replay(object):
             if key in self.seen:
                 return orig(desc, x, dy, dw, pro_scale, pro_shift, pro_relu, dw_zeroed)
             self.seen.add(key)
+            self.new.add(key)
             before = dw.clone() if dw_zeroed else None
             orig(desc, x, dy, dw, pro_scale, pro_shift, pro_relu, dw_zeroed)
             torch.cuda.synchronize()
@@ -213,7 +225,7 @@ class Replay(object):
                 a = a * _f64(pro_scale) + _f64(pro_shift)
                 if pro_relu:
                     a = ko.relu(a)
-            w0 = torch.zeros(tuple(dw.shape), dtype=torch.float64, requires_grad=True)
+            w0 = torch.zeros(tuple(dw.shape), dtype=_DT[0], requires_grad=True)
             _oracle_conv(a, w0, None, desc).backward(_f64(dy))
             if before is not None:
                 assert float(before.abs().max()) == 0.0, "weight-gradient buffer was not cleared before its only writer"
@@ -238,6 +250,7 @@ class Replay(object):
             if key in self.seen:
                 return orig(name, *args)
             self.seen.add(key)
+            self.new.add(key)
             dm_before = dm.clone() if (dm is not None and dm_beta) else None
             orig(name, *args)
             torch.cuda.synchronize()
@@ -255,7 +268,7 @@ class Replay(object):
             y = y.view(int(rows), int(c))
             up = rows_view(dy, ld_dy)
             if mode == 1:
-                up = up * (rows_view(mask_y, ld_y) > 0).to(torch.float64)
+                up = up * (rows_view(mask_y, ld_y) > 0).to(_DT[0])
             out = ko.relu(y) if mode == 2 else y
             (out * up).sum().backward()
             invstd = torch.rsqrt(var + ko.BN_EPSILON)
@@ -290,60 +303,126 @@ class Replay(object):
         return run
 
 
-def test_every_distinct_launch_of_the_benched_step_matches_the_oracle(cuda, monkeypatch):
-    assert os.environ.get("DJ_AUTOTUNE") == "table", "the registered (tile variant, split-K) choices must be the ones that run"
-    from jpeg_detection_resnet_ssd_amd import engine, workloads
-    from jpeg_detection_resnet_ssd_amd import kernels as Kn
-    from jpeg_detection_resnet_ssd_amd.keras import layers as L
-    from test_ssd_gpu import perturb_weights
-    model, sizes = workloads.build_ssd(ARCHI)
-    perturb_weights(model)
-    x, y = workloads.synthetic_batch(ARCHI, sizes, BATCH, fast=True)
-    plan = model._plan(BATCH, True, True)
-    # the table must really cover the plan: an untuned geometry would run the launcher's default instead
-    names = [n for n, _ in type(plan.conv_calls[0][1])._fields_][:15]
-    missing = [d for d, desc, _ in plan.conv_calls
-               if (d,) + tuple(getattr(desc, n) for n in names) not in engine._TUNED]
-    assert not missing, "%d conv launches of the benched plan have no entry in the tuning table" % len(missing)
-    model._upload(plan, x, y)
-    plan.run_forward()           # warm pass (moving statistics, lazy module loads) without the recorder
-    plan.run_backward()
-    torch.cuda.synchronize()
+# One case per BASELINE.json configuration that fits one GPU, at the size its tuning-table entries were measured for
+# (VERDICT r2 item 1): (name, builder, batch, floatx).  Cases of one arithmetic mode share the set of launches already
+# checked, so a geometry that several workloads have in common (the 19x19 stages, the heads) costs oracle time once.
+CASES = [
+    ("deconv_ssd_b32_f32", "ssd:deconv", 32, "float32"),            # the bench workload (north star)
+    ("ssd_custom_b32_f32", "ssd:ssd_custom", 32, "float32"),        # config 3
+    ("deconv_classifier_b64_f32", "cls:deconv", 64, "float32"),     # config 2
+    ("ssd_custom_b32_f16", "ssd:ssd_custom", 32, "float16"),        # config 5 (late_concat_rfa_thinner backbone)
+    ("up_sampling_b32_f16", "ssd:up_sampling", 32, "float16"),      # config 5 (up_sampling_rfa fusion)
+]
+_SEEN = {}      # floatx -> launches already replayed in an earlier case of that mode
 
-    rp = Replay()
-    for lyr in model.layers:
-        if isinstance(lyr, L.BatchNormalization):
-            rp.bn_params[lyr.gamma.param.data_ptr()] = (lyr.gamma.param, lyr.beta.param, lyr.epsilon)
-            assert lyr.epsilon == ko.BN_EPSILON
-    monkeypatch.setattr(Kn, "conv2d_fwd", rp.fwd(Kn.conv2d_fwd))
-    monkeypatch.setattr(Kn, "conv2d_fwd_addrelu", rp.fwd_addrelu(Kn.conv2d_fwd_addrelu))
-    monkeypatch.setattr(Kn, "conv2d_dgrad", rp.dgrad(Kn.conv2d_dgrad))
-    monkeypatch.setattr(Kn, "conv2d_dgrad_bnbwd", rp.dgrad_bnbwd(Kn.conv2d_dgrad_bnbwd))
-    monkeypatch.setattr(Kn, "conv2d_wgrad", rp.wgrad(Kn.conv2d_wgrad))
-    monkeypatch.setattr(L, "call", rp.call(L.call))
-    t0 = time.time()
-    plan.run_forward()
-    plan.run_backward()
-    torch.cuda.synchronize()
-    wall = time.time() - t0
+# fp32: 1e-3 everywhere (max-norm forward, rel-L2 gradients).  float16 (fp16 forward / bf16 gradient operands, fp32
+# accumulate): the operand-rounding tolerances of tests/test_lowp_gpu.py, rel-L2 1.5e-3 forward / 8e-3 gradients; squares of
+# forward values (the BatchNormalization statistics) twice the forward tolerance.  Tensors held in 16 bits in HBM add
+# their storage rounding: 2^-11 per fp16 tensor read or written (activations), 2^-8 per bf16 tensor (gradients), i.e.
+# BatchNormalization's dz, read from a bf16 gradient and a fp16 z and stored as bf16, is bounded by 8e-3 like the GEMM
+# gradients.
+TOLS = {
+    "float32": dict(y_max=TOL, y_l2=TOL, sum_max=TOL, stats_sq=TOL, dx_l2=TOL, dx_max=TOL, dw_l2=TOL, dw_max=TOL, dz_l2=TOL,
+                    dgamma_l2=TOL, dbeta_l2=TOL, scale_max=TOL, shift_max=TOL, shortcut_l2=TOL, nat=3e-5),
+    "float16": dict(y_max=None, y_l2=1.5e-3, sum_max=1.5e-3, stats_sq=3e-3, dx_l2=8e-3, dx_max=None, dw_l2=8e-3, dw_max=None,
+                    dz_l2=8e-3, dgamma_l2=8e-3, dbeta_l2=8e-3, scale_max=TOL, shift_max=TOL, shortcut_l2=8e-3, nat=1.5e-3),
+}
+
+
+def _build(kind, batch):
+    """-> (model, x, y) of one workload, weights perturbed so that no bias / beta sits at its zero initialisation."""
+    from jpeg_detection_resnet_ssd_amd import workloads
+    from test_ssd_gpu import perturb_weights
+    what, archi = kind.split(":")
+    if what == "ssd":
+        model, sizes = workloads.build_ssd(archi)
+        perturb_weights(model)
+        x, y = workloads.synthetic_batch(archi, sizes, batch, fast=True)
+        return model, x, y
+    from jpeg_detection_resnet_ssd_amd.data import synthetic_dct as sd
+    from jpeg_detection_resnet_ssd_amd.keras import backend as K
+    from jpeg_detection_resnet_ssd_amd.keras.optimizers import SGD
+    from jpeg_detection_resnet_ssd_amd.vgg_jpeg_keras.networks.resnet_dct import ResNet50Custom
+    K.clear_session()
+    K.set_random_seed(42)
+    model = ResNet50Custom(weights=None, archi=archi)      # classification_part/vgg_jpeg_keras/networks/resnet_dct.py:603-642
+    model.compile(optimizer=SGD(lr=0.1, momentum=0.9, decay=1e-4, nesterov=True), loss="categorical_crossentropy")
+    perturb_weights(model)
+    x = sd.fast_dct_batch(batch, seed=1234, grid=28, split_chroma=(archi == "deconv"))
+    rng = np.random.default_rng(1234)
+    y = np.zeros((batch, 1000), np.float32)
+    y[np.arange(batch), rng.integers(0, 1000, batch)] = 1.0
+    return model, x, y
+
+
+@pytest.mark.parametrize("name,kind,batch,floatx", CASES, ids=[c[0] for c in CASES])
+def test_every_distinct_launch_of_the_step_matches_the_oracle(name, kind, batch, floatx, cuda, monkeypatch):
+    assert os.environ.get("DJ_AUTOTUNE") == "table", "the registered (tile variant, split-K) choices must be the ones that run"
+    from jpeg_detection_resnet_ssd_amd import engine
+    from jpeg_detection_resnet_ssd_amd import kernels as Kn
+    from jpeg_detection_resnet_ssd_amd.keras import backend as K
+    from jpeg_detection_resnet_ssd_amd.keras import layers as L
+    K.set_floatx(floatx)
+    try:
+        model, x, y = _build(kind, batch)
+        plan = model._plan(batch, True, True)
+        # the table OF THIS MODE must really cover the plan: an untuned geometry would run the launcher's default instead
+        names = [n for n, _ in type(plan.conv_calls[0][1])._fields_][:15]
+        missing = [(d,) + tuple(getattr(desc, n) for n in names) for d, desc, _ in plan.conv_calls
+                   if (d,) + tuple(getattr(desc, n) for n in names) not in engine._TUNED]
+        assert not missing, "%d conv launches of the %s plan have no entry in the %s tuning table: %s" % (
+            len(missing), name, floatx, missing[:4])
+        model._upload(plan, x, y)
+        plan.run_forward()           # warm pass (moving statistics, lazy module loads) without the recorder
+        plan.run_backward()
+        torch.cuda.synchronize()
+
+        rp = Replay(lowp=(floatx != "float32"))
+        rp.seen = _SEEN.setdefault(floatx, set())
+        n_before = len(rp.seen)
+        for lyr in model.layers:
+            if isinstance(lyr, L.BatchNormalization):
+                rp.bn_params[lyr.gamma.param.data_ptr()] = (lyr.gamma.param, lyr.beta.param, lyr.epsilon)
+                assert lyr.epsilon == ko.BN_EPSILON
+        monkeypatch.setattr(Kn, "conv2d_fwd", rp.fwd(Kn.conv2d_fwd))
+        monkeypatch.setattr(Kn, "conv2d_fwd_addrelu", rp.fwd_addrelu(Kn.conv2d_fwd_addrelu))
+        monkeypatch.setattr(Kn, "conv2d_dgrad", rp.dgrad(Kn.conv2d_dgrad))
+        monkeypatch.setattr(Kn, "conv2d_dgrad_bnbwd", rp.dgrad_bnbwd(Kn.conv2d_dgrad_bnbwd))
+        monkeypatch.setattr(Kn, "conv2d_wgrad", rp.wgrad(Kn.conv2d_wgrad))
+        monkeypatch.setattr(L, "call", rp.call(L.call))
+        t0 = time.time()
+        plan.run_forward()
+        plan.run_backward()
+        torch.cuda.synchronize()
+        wall = time.time() - t0
+    finally:
+        K.set_floatx("float32")
 
     kinds = {}
-    for kind, geom, metric, value in rp.rows:
-        kinds.setdefault((kind, metric), []).append((value, geom))
-    print("\nreplayed %d distinct launches of the %s B=%d step in %.0f s (oracle CPU time %.0f s)"
-          % (len(rp.seen), ARCHI, BATCH, wall, rp.cpu_s))
-    for (kind, metric), vals in sorted(kinds.items()):
+    for kind_, geom, metric, value in rp.rows:
+        kinds.setdefault((kind_, metric), []).append((value, geom))
+    new = [s_ for s_ in rp.seen if s_ in rp.new]
+    print("\n%s: replayed %d distinct launches not seen in an earlier %s case (%d known) in %.0f s (oracle CPU time %.0f s)"
+          % (name, len(new), floatx, n_before, wall, rp.cpu_s))
+    for (kind_, metric), vals in sorted(kinds.items()):
         worst = max(vals)
         print("  %-12s %-12s n=%3d  median %.2e  max %.2e  at %s"
-              % (kind, metric, len(vals), float(np.median([v for v, _ in vals])), worst[0], worst[1]))
-    n_kind = {k: sum(1 for s in rp.seen if s[0] == k) for k in ("fwd", "fwd_addrelu", "dgrad", "wgrad", "bn")}
-    # the deconv SSD300 graph: 76 convolutions + 2 transposed ones, 53 BatchNormalization layers
-    assert n_kind["fwd"] >= 25 and n_kind["dgrad"] >= 25 and n_kind["wgrad"] >= 30 and n_kind["bn"] >= 10, n_kind
-    assert n_kind["fwd_addrelu"] >= 3, n_kind
-    # the conv -> BN -> ReLU -> conv chains of the bottleneck blocks take the BatchNormalization backward sums in the GEMM
-    assert sum(1 for s in rp.seen if s[0] == "dgrad" and "bnbwd" in s) >= 5, sorted(s for s in rp.seen if s[0] == "dgrad")
-    # sums measured on their natural scale: fp32 partial sums in double totals stay below 1e-5 of it (measured 9e-6 on
-    # a ReLU-masked layer, where the fp64 oracle and the fp32 engine disagree on the sign of a few pre-activations)
-    bad = [(kind, geom, metric, value) for kind, geom, metric, value in rp.rows
-           if not value <= (3e-5 if metric.endswith("_nat") else TOL)]
+              % (kind_, metric, len(vals), float(np.median([v for v, _ in vals])), worst[0], worst[1]))
+    n_kind = {k: sum(1 for s_ in new if s_[0] == k) for k in ("fwd", "fwd_addrelu", "dgrad", "wgrad", "bn")}
+    if name == "deconv_ssd_b32_f32":
+        # the deconv SSD300 graph: 76 convolutions + 2 transposed ones, 53 BatchNormalization layers
+        assert n_kind["fwd"] >= 25 and n_kind["dgrad"] >= 25 and n_kind["wgrad"] >= 30 and n_kind["bn"] >= 10, n_kind
+        assert n_kind["fwd_addrelu"] >= 3, n_kind
+        # the conv -> BN -> ReLU -> conv chains of the bottleneck blocks take the BatchNormalization backward sums in the GEMM
+        assert sum(1 for s_ in new if s_[0] == "dgrad" and "bnbwd" in s_) >= 5, sorted(s_ for s_ in new if s_[0] == "dgrad")
+    else:
+        # every other workload brings geometries of its own (38x38x64 stages and the small-BN split stages of ssd_custom,
+        # the 28x28 / 14x14 / 7x7 maps of the classifier at batch 64, ...)
+        assert n_kind["fwd"] + n_kind["fwd_addrelu"] >= 8 and n_kind["dgrad"] >= 8 and n_kind["wgrad"] >= 8, n_kind
+    tol = TOLS[floatx]
+    bad = []
+    for kind_, geom, metric, value in rp.rows:
+        bound = tol["nat"] if metric.endswith("_nat") else tol[metric]
+        if bound is not None and not value <= bound:
+            bad.append((kind_, geom, metric, value, bound))
     assert not bad, bad[:10]
