@@ -26,12 +26,15 @@ PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA
 PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s measured with a float4 copy)
 
 
-def conv_bytes(desc):
-    """Algorithmic HBM bytes of one conv launch in any direction: its two fp32 operands read once, its result written once
-    (x, w, y of the geometry; padding columns of a fused predictor-head filter bank are not counted)."""
+def conv_bytes(desc, x_bytes=4, y_bytes=4):
+    """Algorithmic HBM bytes of one conv launch in any direction: its two operands read once, its result written once, each
+    at the width it has in HBM (x / dx and y / dy of the geometry: 4 bytes per element, or 2 where the plan holds the
+    tensor as fp16 / bf16; the weights and their gradient are always fp32; padding columns of a fused predictor-head filter
+    bank are not counted)."""
     out_c = getattr(desc, "algorithmic_out_c", desc.out_c)
-    return 4.0 * (desc.batch * desc.in_h * desc.in_w * desc.in_c + desc.kernel_h * desc.kernel_w * desc.in_c * out_c
-                  + desc.batch * desc.out_h * desc.out_w * out_c)
+    return (float(x_bytes) * desc.batch * desc.in_h * desc.in_w * desc.in_c
+            + 4.0 * desc.kernel_h * desc.kernel_w * desc.in_c * out_c
+            + float(y_bytes) * desc.batch * desc.out_h * desc.out_w * out_c)
 
 
 def conv_flops(desc):
@@ -55,12 +58,21 @@ def measure_conv_kernels(model, plan):
             e0.record()
             r = f(desc, *a, **kw)
             e1.record()
-            extra = 0.0
-            if name == "conv2d_dgrad_bnbwd":     # the BatchNormalization input z is read beside the GEMM operands
-                extra = 4.0 * desc.batch * desc.in_h * desc.in_w * desc.in_c
-            elif name == "conv2d_fwd_addrelu":   # residual operand read, the sum written
-                extra = 8.0 * desc.batch * desc.in_h * desc.in_w * desc.in_c
-            records.append((e0, e1, conv_flops(desc), conv_bytes(desc) + extra))
+            # positional tensors: fwd (x, w, bias, y ...), fwd_addrelu (x, w, bias, y, sc, sh, res, rsc, rsh, sum_out ...),
+            # dgrad[_bnbwd] (dy, w, dx[, z ...]), wgrad (x, dy, dw ...)
+            extra, n_in = 0.0, desc.batch * desc.in_h * desc.in_w * desc.in_c
+            if name in ("conv2d_fwd", "conv2d_fwd_addrelu"):
+                xb, yb = a[0].element_size(), a[3].element_size()
+                if name == "conv2d_fwd_addrelu":   # residual operand read, the sum written
+                    sum_out = a[9] if len(a) > 9 else kw.get("sum_out")
+                    extra = float(a[6].element_size() + (sum_out.element_size() if sum_out is not None else 0)) * n_in
+            elif name in ("conv2d_dgrad", "conv2d_dgrad_bnbwd"):
+                xb, yb = a[2].element_size(), a[0].element_size()
+                if name == "conv2d_dgrad_bnbwd":   # the BatchNormalization input z is read beside the GEMM operands
+                    extra = float(a[3].element_size()) * n_in
+            else:
+                xb, yb = a[0].element_size(), a[1].element_size()
+            records.append((e0, e1, conv_flops(desc), conv_bytes(desc, xb, yb) + extra))
             return r
         setattr(Kn, name, timed)
 

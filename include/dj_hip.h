@@ -41,6 +41,15 @@ const char* dj_last_error(void);
 #define DJ_ABI_VERSION 3
 int dj_abi_version(void);
 
+/* Storage type of a tensor in HBM.  Everything is fp32 unless an entry point's name ends in `_t`: those take, next to
+ * each ACTIVATION / GRADIENT tensor, one of these codes (BASELINE config 5, "fp16-input / fp32-accumulate": under
+ * K.set_floatx('float16') the backbone's conv outputs and block sums are held as fp16, their gradients as bf16 -- the
+ * exponent range gradients need --; weights, their gradients, the optimizer state, BatchNormalization statistics and all
+ * arithmetic outside the MFMA operands stay fp32).  `ld_*` are in ELEMENTS of the tensor they describe. */
+#define DJ_F32 0
+#define DJ_F16 1
+#define DJ_BF16 2
+
 /* Geometry of one keras.layers.Conv2D (third-party; used at
  * L/models/keras_ssd300_dct_j2d_resnet.py:77-96,128-160,483-545,562-675).  TF 'same'
  * padding is resolved by the caller into pad_top/pad_left (asymmetric for even kernels). */
@@ -187,6 +196,27 @@ int dj_conv2d_default_config(int dir, const dj_conv2d_desc* d, int* cfg, int* sp
 int dj_conv2d_nhwc_wgrad(const dj_conv2d_desc* d, const float* x, const float* dy, float* dw,
                          const float* pro_scale, const float* pro_shift, int pro_relu, int dw_zeroed, void* stream);
 
+/* ---- the three convolution GEMMs over tensors that carry their storage type (arithmetic mode 1 only) ----
+ * Same semantics as the float entry points they generalise; a 16-bit operand needs the branch-free kernel's
+ * preconditions (channel counts that are multiples of 32, 16-byte aligned bases, stride-1 or 1x1 input gradients) and is an
+ * error otherwise -- never a silent conversion pass.  A 16-bit RESULT is written by one K range: such a launch is never
+ * split over workgroups, whatever the tuner registered.
+ * dj_conv2d_nhwc_fwd_t = dj_conv2d_nhwc_fwd_ws (res == NULL) / dj_conv2d_nhwc_fwd_addrelu_ws (res != NULL: then pro_relu is
+ * ignored, the residual operand has x's type): x, res fp32 | fp16; y fp32 | fp16 (rounded AFTER the fp32 bias / ReLU /
+ * statistics epilogue); sum_out fp32 | fp16.  Keras call sites: L/models/keras_ssd300_dct_j2d_resnet.py:77-99,128-163. */
+int dj_conv2d_nhwc_fwd_t(const dj_conv2d_desc* d, const void* x, int dt_x, const float* w, const float* bias, void* y,
+                         int dt_y, const float* pro_scale, const float* pro_shift, int pro_relu, int relu, float* stats,
+                         const void* res, int ld_res, const float* res_scale, const float* res_shift, void* sum_out,
+                         int ld_sum, int dt_sum, float* workspace, long workspace_floats, void* stream);
+/* dj_conv2d_nhwc_dgrad (z == NULL) / dj_conv2d_nhwc_dgrad_bnbwd (z != NULL: beta must be 0, bias NULL): dy fp32 | bf16,
+ * dx any type (bf16 for the gradient of a fp16 activation; accumulates in that type when beta & 1), z fp32 | fp16. */
+int dj_conv2d_nhwc_dgrad_t(const dj_conv2d_desc* d, const void* dy, int dt_dy, const float* w, const float* bias, void* dx,
+                           int dt_dx, int beta, const void* z, int ld_z, int dt_z, const float* mean, const float* invstd,
+                           const float* scale, const float* shift, float* partial, void* stream);
+/* dj_conv2d_nhwc_wgrad: x fp32 | fp16, dy fp32 | bf16; dw is the fp32 gradient of the master weights. */
+int dj_conv2d_nhwc_wgrad_t(const dj_conv2d_desc* d, const void* x, int dt_x, const void* dy, int dt_dy, float* dw,
+                           const float* pro_scale, const float* pro_shift, int pro_relu, int dw_zeroed, void* stream);
+
 /* ---- blocked column reductions (two-stage, deterministic) ------------------------- */
 /* Rows of the `partial` buffers written by the *_partial / *_reduce entry points for a
  * [rows][C] operand: partial is [dj_reduce_rows(rows)][2][C] floats. */
@@ -260,6 +290,25 @@ typedef struct dj_copy_part {
   int beta; /* 1: dst += src */
 } dj_copy_part;
 int dj_copy2d_multi(const dj_copy_part* parts, int n_parts, void* stream);
+/* The elementwise passes above over tensors that carry their storage type (each tensor pointer is followed by its DJ_F32 /
+ * DJ_F16 / DJ_BF16 code; any mix; arithmetic in fp32, one rounding where a 16-bit tensor is written).  Same Keras call
+ * sites: BatchNormalization / Activation / Add at L/models/keras_ssd300_dct_j2d_resnet.py:80-99,135-163. */
+int dj_affine_act_t(const void* x, int dt_x, int ldx, const float* scale, const float* shift, const void* res, int dt_res,
+                    int ldres, const float* res_scale, const float* res_shift, void* y, int dt_y, int ldy, long rows, int C,
+                    int relu, void* stream);
+int dj_bn_bwd_reduce_t(const void* dy, int dt_dy, int ld_dy, const void* z, int dt_z, int ld_z, const void* y, int dt_y,
+                       int ld_y, const float* mean, const float* invstd, const float* scale, const float* shift,
+                       int mask_mode, long rows, int C, float* partial, void* stream);
+int dj_bn_bwd_apply_t(const void* dy, int dt_dy, int ld_dy, const void* z, int dt_z, int ld_z, const void* y, int dt_y,
+                      int ld_y, const float* scale, const float* shift, int mask_mode, const float* k0, const float* k1,
+                      const float* k2, void* dz, int dt_dz, int ld_dz, long rows, int C, void* dmasked, int dt_dm, int ld_dm,
+                      int dm_beta, void* stream);
+int dj_relu_bwd_t(const void* dy, int dt_dy, int ld_dy, const void* y, int dt_y, int ld_y, void* dx, int dt_dx, int ld_dx,
+                  long rows, int C, int beta, void* stream);
+/* dst (+)= src with a change of storage type on the way: a 16-bit backbone tensor handed to a layer that works on fp32
+ * (L2Normalization, pooling, Concatenate), and the gradient coming back. */
+int dj_copy2d_t(const void* src, int dt_src, long ld_src, void* dst, int dt_dst, long ld_dst, long rows, long cols, int beta,
+                void* stream);
 /* UpSampling2D() nearest x2 (L/models/...resnet.py:1669) written into a channel slice. */
 int dj_upsample2x(const float* x, int ldx, float* y, int ldy, int B, int H, int W, int C, void* stream);
 

@@ -79,6 +79,19 @@ SIGNATURES = {
     "dj_conv2d_nhwc_dgrad": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, c_int, c_void_p]),
     "dj_conv2d_nhwc_dgrad_bnbwd": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, c_int, FP, FP, FP, FP, FP, c_void_p]),
     "dj_conv2d_nhwc_wgrad": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, c_int, c_int, c_void_p]),
+    "dj_conv2d_nhwc_fwd_t": (c_int, [POINTER(ConvDesc), FP, c_int, FP, FP, FP, c_int, FP, FP, c_int, c_int, FP, FP, c_int, FP, FP,
+                                     FP, c_int, c_int, FP, c_long, c_void_p]),
+    "dj_conv2d_nhwc_dgrad_t": (c_int, [POINTER(ConvDesc), FP, c_int, FP, FP, FP, c_int, c_int, FP, c_int, c_int, FP, FP, FP, FP,
+                                       FP, c_void_p]),
+    "dj_conv2d_nhwc_wgrad_t": (c_int, [POINTER(ConvDesc), FP, c_int, FP, c_int, FP, FP, FP, c_int, c_int, c_void_p]),
+    "dj_affine_act_t": (c_int, [FP, c_int, c_int, FP, FP, FP, c_int, c_int, FP, FP, FP, c_int, c_int, c_long, c_int, c_int,
+                                c_void_p]),
+    "dj_bn_bwd_reduce_t": (c_int, [FP, c_int, c_int, FP, c_int, c_int, FP, c_int, c_int, FP, FP, FP, FP, c_int, c_long, c_int, FP,
+                                   c_void_p]),
+    "dj_bn_bwd_apply_t": (c_int, [FP, c_int, c_int, FP, c_int, c_int, FP, c_int, c_int, FP, FP, c_int, FP, FP, FP, FP, c_int,
+                                  c_int, c_long, c_int, FP, c_int, c_int, c_int, c_void_p]),
+    "dj_relu_bwd_t": (c_int, [FP, c_int, c_int, FP, c_int, c_int, FP, c_int, c_int, c_long, c_int, c_int, c_void_p]),
+    "dj_copy2d_t": (c_int, [FP, c_int, c_long, FP, c_int, c_long, c_long, c_long, c_int, c_void_p]),
     "dj_conv2d_fwd_addrelu_supported": (c_int, [POINTER(ConvDesc)]),
     "dj_conv2d_nhwc_fwd_addrelu": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, FP, FP, c_int, FP, FP, FP, c_int, c_int, FP,
                                            c_void_p]),

@@ -167,10 +167,14 @@ __global__ void dj_relu_rows_kernel(float* y, long rows, int cols, int ld) {
   }
 }
 
-static int extent_bytes(long pixels, long ld, long c) {
-  long b = ((pixels - 1) * ld + c) * 4;
+static int extent_bytes(long pixels, long ld, long c, int es = 4) {
+  long b = ((pixels - 1) * ld + c) * es;
   return (b > 0 && b < 0x7FFFFFF0L) ? (int)b : 0;
 }
+
+// storage types of the tensors of a launch (DJ_F32 / DJ_F16 / DJ_BF16); the float entry points pass all zeros
+static inline int dt_size(int dt) { return dt == DJ_F32 ? 4 : 2; }
+static inline bool dt_ok(int dt) { return dt == DJ_F32 || dt == DJ_F16 || dt == DJ_BF16; }
 
 // reciprocals of the row grid (p.rowH, p.rowW must be set): the kernels decompose a GEMM row into (image, h, w) with a
 // float multiply and a one-step correction instead of integer divisions
@@ -303,11 +307,21 @@ struct FwdResidual {
   int ld_sum = 0;
 };
 
+struct FwdTypes {   // how x (and the residual operand), y and the stored residual sum are held in HBM
+  int x = DJ_F32, y = DJ_F32, sum = DJ_F32;
+};
+
 static int conv_fwd_impl(const dj_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y,
                          const float* pro_scale, const float* pro_shift, int pro_relu, int relu, float* stats,
-                         const FwdResidual& rz, void* stream, float* ws = nullptr, long ws_floats = 0) {
+                         const FwdResidual& rz, void* stream, float* ws = nullptr, long ws_floats = 0,
+                         const FwdTypes& ty = FwdTypes()) {
   if (int rc = check_desc(d)) return rc;
   DJ_CHECK_ARG(x && w && y, "conv fwd: null tensor");
+  const bool io16 = ty.x != DJ_F32 || ty.y != DJ_F32 || ty.sum != DJ_F32;
+  DJ_CHECK_ARG((ty.x == DJ_F32 || ty.x == DJ_F16) && (ty.y == DJ_F32 || ty.y == DJ_F16) && (ty.sum == DJ_F32 || ty.sum == DJ_F16),
+               "conv fwd: activations are held as fp32 or fp16");
+  DJ_CHECK_ARG(!io16 || (dj_compute_mode() == 1 && !rz.bn),
+               "conv fwd: 16-bit tensors need arithmetic mode 1 (float16) and no in-kernel BatchNormalization finalize");
   DJ_CHECK_ARG((pro_scale == nullptr) == (pro_shift == nullptr), "conv fwd: pro_scale/pro_shift must come together");
   hipStream_t s = (hipStream_t)stream;
   DjIgemmParams p;
@@ -340,7 +354,10 @@ static int conv_fwd_impl(const dj_conv2d_desc* d, const float* x, const float* w
   p.vecA = (d->in_c % 4 == 0) && (d->ld_x % 4 == 0) && aligned16(x) &&
            (!pro_scale || (aligned16(pro_scale) && aligned16(pro_shift)));
   p.vecB = (d->out_c % 4 == 0) && aligned16(w);
-  p.a_bytes = extent_bytes((long)d->batch * d->in_h * d->in_w, d->ld_x, d->in_c);
+  p.a_bytes = extent_bytes((long)d->batch * d->in_h * d->in_w, d->ld_x, d->in_c, dt_size(ty.x));
+  p.a_dt = ty.x;
+  p.c_dt = ty.y;
+  p.sum_dt = ty.sum;
   if (rz.res) {
     p.A2 = rz.res;
     p.ldsrc2 = rz.ld_res;
@@ -348,8 +365,8 @@ static int conv_fwd_impl(const dj_conv2d_desc* d, const float* x, const float* w
     p.pro_shift2 = rz.res_shift;
     p.sum_out = rz.sum_out;
     p.ld_sum = rz.ld_sum;
-    p.a2_bytes = extent_bytes((long)d->batch * d->in_h * d->in_w, rz.ld_res, d->in_c);
-    p.sum_bytes = rz.sum_out ? extent_bytes((long)d->batch * d->in_h * d->in_w, rz.ld_sum, d->in_c) : 0;
+    p.a2_bytes = extent_bytes((long)d->batch * d->in_h * d->in_w, rz.ld_res, d->in_c, dt_size(ty.x));
+    p.sum_bytes = rz.sum_out ? extent_bytes((long)d->batch * d->in_h * d->in_w, rz.ld_sum, d->in_c, dt_size(ty.sum)) : 0;
   }
   p.b_bytes = extent_bytes((long)p.K, d->out_c, d->out_c);
   if (rz.bn) {
@@ -382,6 +399,7 @@ static int conv_fwd_impl(const dj_conv2d_desc* d, const float* x, const float* w
   int cfg = choose_cfg(p.M, p.N, p.K, !wants_stats, &splits);
   tune_lookup(wants_stats ? 4 : 0, d, &cfg, &splits);
   if (wants_stats) splits = 1;
+  if (ty.y != DJ_F32) splits = 1;   // a 16-bit result is written by one K range (no slabs, no atomics)
   p.kchunk = dj_cdiv(dj_cdiv(p.K, splits), DJ_BK) * DJ_BK;
   splits = dj_cdiv(p.K, p.kchunk);
   // split-K through slabs in the caller's workspace + a fixed-order reduction (deterministic), when they fit
@@ -412,6 +430,8 @@ static int conv_fwd_impl(const dj_conv2d_desc* d, const float* x, const float* w
     DJ_CHECK_ARG(dj_fast_mode_fwd(p) == 3, "conv fwd (residual add): the branch-free kernel's preconditions do not hold "
                                            "(channels %% 32, 16-byte aligned tensors)");
   }
+  DJ_CHECK_ARG(!io16 || dj_fast_mode_fwd(p) != 0, "conv fwd: 16-bit tensors need the branch-free kernel's preconditions "
+                                                  "(in_c %% 32 == 0, out_c %% 4 == 0, 16-byte aligned tensors)");
   if (int rc = dj_launch_cfg<0, 0>(cfg, p, splits, s)) return rc;
   if (slabs) return launch_splitk_reduce(ws, splits, p.slab_stride, p.M, p.N, bias, relu, y, d->ld_y, stats, s);
   if (splits > 1 && relu) {
@@ -494,7 +514,8 @@ extern "C" int dj_conv2d_fwd_addrelu_supported(const dj_conv2d_desc* d) {
 static int conv_fwd_addrelu_impl(const dj_conv2d_desc* d, const float* x, const float* w, const float* bias,
                                  float* y, const float* pro_scale, const float* pro_shift, const float* res,
                                  int ld_res, const float* res_scale, const float* res_shift, float* sum_out,
-                                 int ld_sum, int relu, float* stats, float* ws, long ws_floats, void* stream) {
+                                 int ld_sum, int relu, float* stats, float* ws, long ws_floats, void* stream,
+                                 const FwdTypes& ty = FwdTypes()) {
   DJ_CHECK_ARG(d && dj_conv2d_fwd_addrelu_supported(d), "conv fwd (residual add): needs a 1x1 stride-1 unpadded conv with "
                                                          "in_c %% 32 == 0");
   DJ_CHECK_ARG(res && pro_scale && pro_shift, "conv fwd (residual add): res, pro_scale and pro_shift are required");
@@ -510,7 +531,29 @@ static int conv_fwd_addrelu_impl(const dj_conv2d_desc* d, const float* x, const 
   rz.res_shift = res_shift;
   rz.sum_out = sum_out;
   rz.ld_sum = ld_sum;
-  return conv_fwd_impl(d, x, w, bias, y, pro_scale, pro_shift, 1, relu, stats, rz, stream, ws, ws_floats);
+  return conv_fwd_impl(d, x, w, bias, y, pro_scale, pro_shift, 1, relu, stats, rz, stream, ws, ws_floats, ty);
+}
+
+// Forward convolution over tensors that carry their storage type (include/dj_hip.h): the superset of dj_conv2d_nhwc_fwd_ws
+// (res == NULL) and dj_conv2d_nhwc_fwd_addrelu_ws.
+extern "C" int dj_conv2d_nhwc_fwd_t(const dj_conv2d_desc* d, const void* x, int dt_x, const float* w, const float* bias, void* y,
+                                    int dt_y, const float* pro_scale, const float* pro_shift, int pro_relu, int relu,
+                                    float* stats, const void* res, int ld_res, const float* res_scale,
+                                    const float* res_shift, void* sum_out, int ld_sum, int dt_sum, float* workspace,
+                                    long workspace_floats, void* stream) {
+  DJ_CHECK_ARG(dt_ok(dt_x) && dt_ok(dt_y) && dt_ok(dt_sum), "conv fwd: unknown storage type");
+  DJ_CHECK_ARG(workspace_floats >= 0 && (workspace != nullptr || workspace_floats == 0), "conv fwd: bad workspace");
+  FwdTypes ty;
+  ty.x = dt_x;
+  ty.y = dt_y;
+  ty.sum = sum_out ? dt_sum : DJ_F32;
+  if (res)
+    return conv_fwd_addrelu_impl(d, (const float*)x, w, bias, (float*)y, pro_scale, pro_shift, (const float*)res, ld_res,
+                                 res_scale, res_shift, (float*)sum_out, ld_sum, relu, stats, workspace, workspace_floats,
+                                 stream, ty);
+  DJ_CHECK_ARG(!sum_out, "conv fwd: sum_out without res");
+  return conv_fwd_impl(d, (const float*)x, w, bias, (float*)y, pro_scale, pro_shift, pro_relu, relu, stats, FwdResidual(),
+                       stream, workspace, workspace_floats, ty);
 }
 
 extern "C" int dj_conv2d_nhwc_fwd_addrelu(const dj_conv2d_desc* d, const float* x, const float* w, const float* bias,
@@ -534,6 +577,7 @@ extern "C" int dj_conv2d_nhwc_fwd_addrelu_ws(const dj_conv2d_desc* d, const floa
 
 struct DgradBnBwd {   // dj_conv2d_nhwc_dgrad_bnbwd: see include/dj_hip.h
   const float* z;
+  int dt_z;
   int ld_z;
   const float* mean;
   const float* invstd;
@@ -543,9 +587,13 @@ struct DgradBnBwd {   // dj_conv2d_nhwc_dgrad_bnbwd: see include/dj_hip.h
 };
 
 static int conv_dgrad_impl(const dj_conv2d_desc* d, const float* dy, const float* w, const float* bias, float* dx, int beta,
-                           const DgradBnBwd* bnb, void* stream) {
+                           const DgradBnBwd* bnb, void* stream, int dt_dy = DJ_F32, int dt_dx = DJ_F32) {
   if (int rc = check_desc(d)) return rc;
   DJ_CHECK_ARG(dy && w && dx, "conv dgrad: null tensor");
+  const bool io16 = dt_dy != DJ_F32 || dt_dx != DJ_F32 || (bnb && bnb->dt_z != DJ_F32);
+  DJ_CHECK_ARG((dt_dy == DJ_F32 || dt_dy == DJ_BF16) && (!bnb || bnb->dt_z == DJ_F32 || bnb->dt_z == DJ_F16),
+               "conv dgrad: gradients are held as fp32 or bf16, the BatchNormalization input as fp32 or fp16");
+  DJ_CHECK_ARG(!io16 || dj_compute_mode() == 1, "conv dgrad: 16-bit tensors need arithmetic mode 1 (float16)");
   const bool one_k_range = (beta & DJ_DGRAD_NO_SPLIT) != 0;   // no split-K: no arrival-order arithmetic
   beta &= 1;
   hipStream_t s = (hipStream_t)stream;
@@ -554,7 +602,8 @@ static int conv_dgrad_impl(const dj_conv2d_desc* d, const float* dy, const float
   if (bnb) {
     p.bnb_z = bnb->z;
     p.bnb_ldz = bnb->ld_z;
-    p.bnb_zbytes = extent_bytes((long)d->batch * d->in_h * d->in_w, bnb->ld_z, d->in_c);
+    p.bnb_zbytes = extent_bytes((long)d->batch * d->in_h * d->in_w, bnb->ld_z, d->in_c, dt_size(bnb->dt_z));
+    p.bnb_zdt = bnb->dt_z;
     DJ_CHECK_ARG(p.bnb_zbytes > 0, "conv dgrad + BN backward statistics: z of 2 GiB or more");
     p.bnb_mean = bnb->mean;
     p.bnb_invstd = bnb->invstd;
@@ -575,8 +624,11 @@ static int conv_dgrad_impl(const dj_conv2d_desc* d, const float* dy, const float
   p.beta = beta;
   p.vecA = (d->out_c % 4 == 0) && (d->ld_y % 4 == 0) && aligned16(dy);
   p.vecB = (d->out_c % 4 == 0) && aligned16(w);
-  p.a_bytes = extent_bytes((long)d->batch * d->out_h * d->out_w, d->ld_y, d->out_c);
+  p.a_bytes = extent_bytes((long)d->batch * d->out_h * d->out_w, d->ld_y, d->out_c, dt_size(dt_dy));
   p.b_bytes = extent_bytes((long)d->kernel_h * d->kernel_w * d->in_c, d->out_c, d->out_c);
+  p.a_dt = dt_dy;
+  p.c_dt = dt_dx;
+  const int es_dx = dt_size(dt_dx);
   const long in_pixels = (long)d->batch * d->in_h * d->in_w;
   bool strided_1x1 = d->kernel_h == 1 && d->kernel_w == 1 && d->pad_top == 0 && d->pad_left == 0 &&
                      (d->stride_h > 1 || d->stride_w > 1) && d->stride_h == d->stride_w && bias == nullptr;
@@ -601,7 +653,7 @@ static int conv_dgrad_impl(const dj_conv2d_desc* d, const float* dy, const float
     p.cW = d->in_w;
     p.cS = d->stride_h;
     if (!beta) {
-      hipError_t e = hipMemset2DAsync(dx, (size_t)d->ld_x * 4, 0, (size_t)d->in_c * 4, (size_t)in_pixels, s);
+      hipError_t e = hipMemset2DAsync(dx, (size_t)d->ld_x * es_dx, 0, (size_t)d->in_c * es_dx, (size_t)in_pixels, s);
       if (e != hipSuccess) {
         dj_set_error("conv dgrad: memset: %s", hipGetErrorString(e));
         return DJ_ERR_HIP;
@@ -610,6 +662,8 @@ static int conv_dgrad_impl(const dj_conv2d_desc* d, const float* dy, const float
     int cfg = choose_cfg(p.M, p.N, p.K, false, &splits);
     tune_lookup(1, d, &cfg, &splits);
     p.kchunk = dj_cdiv(p.K, DJ_BK) * DJ_BK;
+    DJ_CHECK_ARG(!io16 || (fast_mode<0, 1>(p)) != 0, "conv dgrad (strided 1x1): 16-bit tensors need the branch-free kernel's "
+                                                   "preconditions (channels %% 32, 16-byte aligned tensors)");
     return dj_launch_cfg<0, 1>(cfg, p, 1, s);
   }
   p.M = (int)in_pixels;
@@ -624,9 +678,11 @@ static int conv_dgrad_impl(const dj_conv2d_desc* d, const float* dy, const float
   // the launch that also takes BatchNormalization backward statistics runs the EPI twin and is never split: a tuner
   // entry of its own (direction 9), falling back to the plain input gradient's tile variant
   if (!(bnb && tune_lookup(9, d, &cfg, &splits))) tune_lookup(1, d, &cfg, &splits);
-  if (one_k_range) splits = 1;
+  if (one_k_range || dt_dx != DJ_F32) splits = 1;   // (a 16-bit result is written by one K range: no atomics)
   p.kchunk = dj_cdiv(dj_cdiv(p.K, splits), DJ_BK) * DJ_BK;
   splits = dj_cdiv(p.K, p.kchunk);
+  DJ_CHECK_ARG(!io16 || (fast_mode<1, 1>(p)) != 0, "conv dgrad: 16-bit tensors need the branch-free kernel's preconditions "
+                                                 "(stride 1, channels %% 32, 16-byte aligned tensors)");
   if (splits > 1) {
     p.atomic = 1;
     if (!beta) {
@@ -652,16 +708,35 @@ extern "C" int dj_conv2d_nhwc_dgrad_bnbwd(const dj_conv2d_desc* d, const float* 
   DJ_CHECK_ARG(z && mean && invstd && partial, "conv dgrad + BN backward statistics: null tensor");
   DJ_CHECK_ARG((scale == nullptr) == (shift == nullptr), "conv dgrad + BN backward statistics: scale/shift must come together");
   DJ_CHECK_ARG(d && ld_z >= d->in_c, "conv dgrad + BN backward statistics: ld_z < in_c");
-  DgradBnBwd b{z, ld_z, mean, invstd, scale, shift, partial};
+  DgradBnBwd b{z, DJ_F32, ld_z, mean, invstd, scale, shift, partial};
   // one K range per tile, no accumulation: the accumulator of a tile IS the gradient the statistics are taken of
   return conv_dgrad_impl(d, dy, w, nullptr, dx, DJ_DGRAD_NO_SPLIT, &b, stream);
 }
 
-extern "C" int dj_conv2d_nhwc_wgrad(const dj_conv2d_desc* d, const float* x, const float* dy, float* dw,
-                                    const float* pro_scale, const float* pro_shift, int pro_relu, int dw_zeroed,
-                                    void* stream) {
+// Input gradient over tensors that carry their storage type: the superset of dj_conv2d_nhwc_dgrad (z == NULL) and
+// dj_conv2d_nhwc_dgrad_bnbwd.
+extern "C" int dj_conv2d_nhwc_dgrad_t(const dj_conv2d_desc* d, const void* dy, int dt_dy, const float* w, const float* bias,
+                                      void* dx, int dt_dx, int beta, const void* z, int ld_z, int dt_z, const float* mean,
+                                      const float* invstd, const float* scale, const float* shift, float* partial,
+                                      void* stream) {
+  DJ_CHECK_ARG(dt_ok(dt_dy) && dt_ok(dt_dx) && dt_ok(dt_z), "conv dgrad: unknown storage type");
+  if (!z) return conv_dgrad_impl(d, (const float*)dy, w, bias, (float*)dx, beta, nullptr, stream, dt_dy, dt_dx);
+  DJ_CHECK_ARG(mean && invstd && partial, "conv dgrad + BN backward statistics: null tensor");
+  DJ_CHECK_ARG((scale == nullptr) == (shift == nullptr), "conv dgrad + BN backward statistics: scale/shift must come together");
+  DJ_CHECK_ARG(d && ld_z >= d->in_c && !bias && !(beta & 1), "conv dgrad + BN backward statistics: ld_z < in_c, or a bias / "
+                                                              "an accumulating launch");
+  DgradBnBwd b{(const float*)z, dt_z, ld_z, mean, invstd, scale, shift, partial};
+  return conv_dgrad_impl(d, (const float*)dy, w, nullptr, (float*)dx, DJ_DGRAD_NO_SPLIT, &b, stream, dt_dy, dt_dx);
+}
+
+static int conv_wgrad_impl(const dj_conv2d_desc* d, const float* x, const float* dy, float* dw, const float* pro_scale,
+                           const float* pro_shift, int pro_relu, int dw_zeroed, void* stream, int dt_x, int dt_dy) {
   if (int rc = check_desc(d)) return rc;
   DJ_CHECK_ARG(x && dy && dw, "conv wgrad: null tensor");
+  const bool io16 = dt_x != DJ_F32 || dt_dy != DJ_F32;
+  DJ_CHECK_ARG((dt_x == DJ_F32 || dt_x == DJ_F16) && (dt_dy == DJ_F32 || dt_dy == DJ_BF16),
+               "conv wgrad: activations are held as fp32 or fp16, gradients as fp32 or bf16");
+  DJ_CHECK_ARG(!io16 || dj_compute_mode() == 1, "conv wgrad: 16-bit tensors need arithmetic mode 1 (float16)");
   DJ_CHECK_ARG((pro_scale == nullptr) == (pro_shift == nullptr), "conv wgrad: pro_scale/pro_shift must come together");
   hipStream_t s = (hipStream_t)stream;
   DjIgemmParams p;
@@ -688,8 +763,10 @@ extern "C" int dj_conv2d_nhwc_wgrad(const dj_conv2d_desc* d, const float* x, con
   p.vecA = (d->in_c % 4 == 0) && (d->ld_x % 4 == 0) && aligned16(x) &&
            (!pro_scale || (aligned16(pro_scale) && aligned16(pro_shift)));
   p.vecB = (d->out_c % 4 == 0) && (d->ld_y % 4 == 0) && aligned16(dy);
-  p.a_bytes = extent_bytes((long)d->batch * d->in_h * d->in_w, d->ld_x, d->in_c);
-  p.b_bytes = extent_bytes((long)d->batch * d->out_h * d->out_w, d->ld_y, d->out_c);
+  p.a_bytes = extent_bytes((long)d->batch * d->in_h * d->in_w, d->ld_x, d->in_c, dt_size(dt_x));
+  p.b_bytes = extent_bytes((long)d->batch * d->out_h * d->out_w, d->ld_y, d->out_c, dt_size(dt_dy));
+  p.a_dt = dt_x;
+  p.b_dt = dt_dy;
   // tile by the (taps*Cin) x Cout extent only -- the pixel reduction is split over blockIdx.y to fill the chip
   int splits = 1;
   int cfg;
@@ -718,7 +795,24 @@ extern "C" int dj_conv2d_nhwc_wgrad(const dj_conv2d_desc* d, const float* x, con
       }
     }
   }
+  DJ_CHECK_ARG(!io16 || (fast_mode<2, 0>(p)) != 0, "conv wgrad: 16-bit tensors need the branch-free kernel's preconditions "
+                                                 "(channels %% 4, 16-byte aligned tensors)");
   return dj_launch_cfg<2, 0>(cfg, p, splits, s);
+}
+
+extern "C" int dj_conv2d_nhwc_wgrad(const dj_conv2d_desc* d, const float* x, const float* dy, float* dw,
+                                    const float* pro_scale, const float* pro_shift, int pro_relu, int dw_zeroed,
+                                    void* stream) {
+  return conv_wgrad_impl(d, x, dy, dw, pro_scale, pro_shift, pro_relu, dw_zeroed, stream, DJ_F32, DJ_F32);
+}
+
+// Weight gradient over tensors that carry their storage type (dw is always the fp32 gradient of the master weights).
+extern "C" int dj_conv2d_nhwc_wgrad_t(const dj_conv2d_desc* d, const void* x, int dt_x, const void* dy, int dt_dy, float* dw,
+                                      const float* pro_scale, const float* pro_shift, int pro_relu, int dw_zeroed,
+                                      void* stream) {
+  DJ_CHECK_ARG(dt_ok(dt_x) && dt_ok(dt_dy), "conv wgrad: unknown storage type");
+  return conv_wgrad_impl(d, (const float*)x, (const float*)dy, dw, pro_scale, pro_shift, pro_relu, dw_zeroed, stream, dt_x,
+                         dt_dy);
 }
 
 extern "C" int dj_conv2d_default_config(int dir, const dj_conv2d_desc* d, int* cfg, int* splits) {

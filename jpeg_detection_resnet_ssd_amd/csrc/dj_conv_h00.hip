@@ -1,4 +1,4 @@
-// Reduced-precision kernel instantiations of the forward GEMM.
+// Reduced-precision kernel instantiations: forward GEMM, fp32 activations.
 #include "dj_conv_launch_h16.h"
 
-template int dj_launch_lowp<0, 0>(int, const DjIgemmParams&, int, hipStream_t, int, int);
+template int dj_launch_lowp_io<0, 0, 0, 0>(int, const DjIgemmParams&, int, hipStream_t, int, int);

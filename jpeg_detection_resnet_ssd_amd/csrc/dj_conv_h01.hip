@@ -1,4 +1,4 @@
-// Reduced-precision kernel instantiations of the strided 1x1 input gradient (compact GEMM).
+// Reduced-precision kernel instantiations: strided 1x1 input gradient (compact GEMM + scatter), fp32 dy.
 #include "dj_conv_launch_h16.h"
 
-template int dj_launch_lowp<0, 1>(int, const DjIgemmParams&, int, hipStream_t, int, int);
+template int dj_launch_lowp_io<0, 1, 0, 0>(int, const DjIgemmParams&, int, hipStream_t, int, int);

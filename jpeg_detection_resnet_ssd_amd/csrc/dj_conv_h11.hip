@@ -1,4 +1,4 @@
-// Reduced-precision kernel instantiations of the input-gradient GEMM.
+// Reduced-precision kernel instantiations: input-gradient GEMM, fp32 dy.
 #include "dj_conv_launch_h16.h"
 
-template int dj_launch_lowp<1, 1>(int, const DjIgemmParams&, int, hipStream_t, int, int);
+template int dj_launch_lowp_io<1, 1, 0, 0>(int, const DjIgemmParams&, int, hipStream_t, int, int);

@@ -85,6 +85,10 @@ struct DjIgemmParams {
   const float* bnb_invstd;
   const float* bnb_scale;   // [N] or null (no ReLU behind the BatchNormalization: nothing is masked)
   const float* bnb_shift;
+  // Storage types of the tensors in HBM, 0 fp32 / 1 fp16 / 2 bf16 (dj_igemm_h16.h; the fp32 kernels only know 0): A (and
+  // A2) and B select a kernel instantiation, the others are looked at once per tile.  With a 16-bit operand the pointer
+  // fields above are reinterpreted; ld* stay in elements, *_bytes are real byte extents.
+  int a_dt, b_dt, c_dt, sum_dt, bnb_zdt;
 };
 
 template <int BM, int BN, int WM, int WN, int AM, int BMD>
@@ -226,12 +230,68 @@ __device__ __forceinline__ void dj_store_full_tile(float* ubase, unsigned lane_b
     }
 }
 
+// The same for a C tensor held in 16 bits (c_dt 1 fp16 / 2 bf16; never atomic: a 16-bit result is written by one K range).
+// A lane holds one column of four consecutive rows; neighbouring lanes (columns n, n + 1) swap half of their rounded
+// values so that each stores two packed 32-bit words -- the even lane rows 0-1, the odd lane rows 2-3 of the group --
+// instead of four 2-byte pieces.
+__device__ __forceinline__ unsigned dj_pack16(float lo, float hi, int dt) {
+  if (dt == 1) {
+    const _Float16 a = (_Float16)lo, b = (_Float16)hi;
+    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+  }
+  const __bf16 a = (__bf16)lo, b = (__bf16)hi;
+  return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+__device__ __forceinline__ float dj_widen16(unsigned short u, int dt) {
+  return dt == 1 ? (float)__builtin_bit_cast(_Float16, u) : __builtin_bit_cast(float, (unsigned)u << 16);
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void dj_store_full_tile16(char* ubase, unsigned lane_byte, int l31, const f32x16 (&acc)[TM][TN],
+                                                     const float (&bv)[TN], int ldc, bool beta, bool relu, int dt) {
+  const size_t row_bytes = (size_t)ldc * 2;
+  const bool odd = (l31 & 1) != 0;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      char* rowb = ubase + (size_t)(i * 32 + 8 * g) * row_bytes;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = acc[i][j][4 * g + q] + bv[j];
+        if (beta) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            v[q] += dj_widen16(*reinterpret_cast<const unsigned short*>(rowb + q * row_bytes + j * 64 + lane_byte), dt);
+        }
+        if (relu) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) asm("v_max_f32_e32 %0, 0, %1" : "=v"(v[q]) : "v"(v[q]));
+        }
+        const unsigned p01 = dj_pack16(v[0], v[1], dt), p23 = dj_pack16(v[2], v[3], dt);
+        // even lane: keeps rows 0-1, hands rows 2-3 to its odd neighbour and gets that lane's rows 0-1
+        const unsigned got = (unsigned)__shfl_xor((int)(odd ? p01 : p23), 1);
+        const unsigned mine = odd ? p23 : p01;
+        // word of row r: (column n, column n + 1) = (even lane's value, odd lane's value)
+        const unsigned w0 = odd ? ((got & 0xFFFFu) | (mine << 16)) : ((mine & 0xFFFFu) | (got << 16));
+        const unsigned w1 = odd ? ((got >> 16) | (mine & 0xFFFF0000u)) : ((mine >> 16) | (got & 0xFFFF0000u));
+        char* base = rowb + (odd ? 2 : 0) * row_bytes + j * 64 + (lane_byte & ~3u);
+        *reinterpret_cast<unsigned*>(base) = w0;
+        *reinterpret_cast<unsigned*>(base + row_bytes) = w1;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // Shared epilogue: optional per-tile BatchNormalization statistics of the raw accumulator, then
 // bias / accumulate / ReLU / (atomic) store with an optional strided-pixel row map.
 // BNB: the kernel may be asked for BatchNormalization backward statistics (DjIgemmParams::bnb_z) -- only the
 // input-gradient GEMM is; compiled into every kernel the extra code and its six parameters cost the others registers
 // (128x128 forward variants 160 -> 180 VGPRs, i.e. three waves per SIMD -> two; the residual-add variants 26-42 SGPR spills)
-template <int BM, int BN, int WM, int WN, bool BNB = false>
+// IO16: the kernel may be handed 16-bit tensors (c_dt / bnb_zdt: the reduced-precision kernels of dj_igemm_h16.h only)
+template <int BM, int BN, int WM, int WN, bool BNB = false, bool IO16 = false>
 __device__ __forceinline__ void dj_igemm_epilogue(const DjIgemmParams& p, f32x16 (&acc)[BM / (32 * WM)][BN / (32 * WN)],
                                                   float* smem, int tile_m, int m0, int n0, int ky) {
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
@@ -258,19 +318,25 @@ __device__ __forceinline__ void dj_igemm_epilogue(const DjIgemmParams& p, f32x16
         // 28 us on a 2888-tile launch): rows past M lie past the descriptor's extent and read as zero; a column past N
         // reads some other finite element of z into a lane whose accumulators are zero and whose sums are not stored
         const __amdgpu_buffer_rsrc_t rZ = __builtin_amdgcn_make_buffer_rsrc((void*)p.bnb_z, 0, p.bnb_zbytes, 0x00020000);
-        const unsigned row_b = (unsigned)p.bnb_ldz * 4u;
+        const bool z16 = IO16 && p.bnb_zdt != 0;                  // z held as fp16 (wave-uniform)
+        const unsigned zes = z16 ? 2u : 4u;
+        const unsigned row_b = (unsigned)p.bnb_ldz * zes;
         // eight values at a time: left to itself the compiler issues all 16 * TM * TN loads of the tile first, and the
         // registers that takes cost the whole kernel a wave per SIMD (128x128: 160 -> 184 VGPRs)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          const unsigned lane_b = (unsigned)(m0 + (wm * TM + i) * 32 + 4 * lh) * row_b + (unsigned)n * 4u;
+          const unsigned lane_b = (unsigned)(m0 + (wm * TM + i) * 32 + 4 * lh) * row_b + (unsigned)n * zes;
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             float zz[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
-              zz[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                    rZ, (int)(lane_b + (unsigned)((r & 3) + 8 * (2 * h + (r >> 2))) * row_b), 0, 0));
+            for (int r = 0; r < 8; ++r) {
+              const int zoff = (int)(lane_b + (unsigned)((r & 3) + 8 * (2 * h + (r >> 2))) * row_b);
+              if (z16)
+                zz[r] = (float)__builtin_bit_cast(_Float16, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rZ, zoff, 0, 0));
+              else
+                zz[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rZ, zoff, 0, 0));
+            }
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
               const float g = (zz[r] * sc + sh > 0.f) ? acc[i][j][8 * h + r] : 0.f;
@@ -336,7 +402,51 @@ __device__ __forceinline__ void dj_igemm_epilogue(const DjIgemmParams& p, f32x16
   }
 
   float* const Cb = p.C + (size_t)ky * p.slab_stride;   // ky: this workgroup's K chunk
-  if (p.cmap == 0 && m0 + BM <= p.M && n0 + BN <= p.N) {
+  if (IO16 && p.c_dt != 0) {
+    // C held in 16 bits: one K range per tile (the launcher never splits such a launch), no atomics
+    const int dt = p.c_dt;
+    char* const C16 = reinterpret_cast<char*>(p.C);
+    if (p.cmap == 0 && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldc & 1) == 0) {
+      float bv[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[j] = p.bias ? p.bias[n0 + (wn * TN + j) * 32 + l31] : 0.f;
+      const int uwave = __builtin_amdgcn_readfirstlane(wave);
+      const int uwm = uwave / WN, uwn = uwave % WN;
+      char* ubase = C16 + ((size_t)(m0 + uwm * TM * 32) * p.ldc + (n0 + uwn * TN * 32)) * 2;
+      const unsigned lane_byte = (unsigned)(4 * lh * p.ldc + l31) * 2u;
+      dj_store_full_tile16<TM, TN>(ubase, lane_byte, l31, acc, bv, p.ldc, p.beta != 0, p.relu != 0, dt);
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m >= p.M) continue;
+          size_t rowoff;
+          if (p.cmap == 0) {
+            rowoff = (size_t)m * p.ldc;
+          } else {
+            int img = m / (p.cgH * p.cgW);
+            int rem = m - img * (p.cgH * p.cgW);
+            int h = rem / p.cgW;
+            int w = rem - h * p.cgW;
+            rowoff = (size_t)((img * p.cH + h * p.cS) * p.cW + w * p.cS) * p.ldc;
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            int n = n0 + (wn * TN + j) * 32 + l31;
+            if (n >= p.N) continue;
+            float v = acc[i][j][r];
+            unsigned short* dst = reinterpret_cast<unsigned short*>(C16 + (rowoff + n) * 2);
+            if (p.bias) v += p.bias[n];
+            if (p.beta) v += dj_widen16(*dst, dt);
+            if (p.relu) v = fmaxf(v, 0.f);
+            *dst = (unsigned short)(dj_pack16(v, 0.f, dt) & 0xFFFFu);
+          }
+        }
+      }
+    }
+  } else if (p.cmap == 0 && m0 + BM <= p.M && n0 + BN <= p.N) {
     float bv[TN];
     const bool add_bias = p.bias && (!p.atomic || ky == 0);
 #pragma unroll

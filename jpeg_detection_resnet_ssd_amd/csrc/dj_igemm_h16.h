@@ -21,6 +21,15 @@
 // BatchNormalization(+ReLU) prologue in fp32 before the rounding, XCD-aware tile order, split-K) and the epilogue are
 // those of the fp32 kernel.
 //
+// Operands in HBM (round 3, BASELINE config 5 proper): AT / BT name how the gathered operand A (and the residual operand
+// A2) and the operand B are STORED -- 0 fp32, 1 fp16, 2 bf16 (DJ_F32 / DJ_F16 / DJ_BF16 of include/dj_hip.h).  Activations
+// are kept as fp16 and their gradients as bf16 inside the backbone: a thread's 4-element piece is then ONE 8-byte buffer
+// load, stays in two registers until it goes to LDS (half the staging registers, half the bytes in flight per element),
+// is widened to fp32 only where a prologue has arithmetic to do, and goes to LDS untouched when it already has the
+// MFMA's type and there is no prologue (block sums in the forward pass, dy in both gradient GEMMs).  Weights are always
+// the fp32 master copy.  The result C, the stored residual sum and the BatchNormalization input z of the statistics
+// epilogue carry their types at run time (DjIgemmParams::c_dt / sum_dt / bnb_zdt): they are touched once per tile.
+//
 // BK: with 16-bit MFMAs a 32-deep K-step is 2-8 matrix instructions per wave (64-256 cycles) between two barriers, and
 // the loads of the next step have just that long to land: a workgroup's K-loop is a chain of global-load latencies
 // (19x19 3x3 256->256 forward, 64x64 tiles: 72 steps of ~0.9 us = the 68 us the launch takes).  BK = 64 halves the
@@ -35,6 +44,43 @@ typedef short dj_s16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 dj_half8 __attribute__((ext_vector_type(8)));
 typedef __bf16 dj_bf16x8 __attribute__((ext_vector_type(8)));
 typedef short __attribute__((address_space(3))) dj_lds_short;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// A thread's 4-element piece of an operand between its buffer load and its LDS store, as the operand is stored in HBM
+template <int DT>
+struct DjRaw {
+  using type = f32x4;
+};
+template <>
+struct DjRaw<1> {
+  using type = u32x2;
+};
+template <>
+struct DjRaw<2> {
+  using type = u32x2;
+};
+
+template <int DT>
+__device__ __forceinline__ typename DjRaw<DT>::type dj_buf_ldraw(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  if constexpr (DT == 0) {
+    return dj_buf_ld4(r, off);
+  } else {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0));
+  }
+}
+
+template <int DT>
+__device__ __forceinline__ f32x4 dj_raw_to_f32(typename DjRaw<DT>::type v) {
+  if constexpr (DT == 0) {
+    return v;
+  } else if constexpr (DT == 1) {
+    const dj_half4 h = __builtin_bit_cast(dj_half4, v);
+    return f32x4{(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+  } else {   // bf16: the upper half of the fp32 word
+    return f32x4{__builtin_bit_cast(float, v.x << 16), __builtin_bit_cast(float, v.x & 0xFFFF0000u),
+                 __builtin_bit_cast(float, v.y << 16), __builtin_bit_cast(float, v.y & 0xFFFF0000u)};
+  }
+}
 
 template <int BM, int BN, int AM, int BMD, int BK = 32>
 struct DjH16Cfg {
@@ -66,9 +112,16 @@ __device__ __forceinline__ dj_short4 dj_round4(f32x4 v) {
 // step earlier) goes to LDS: a load has a full K-step longer to land (small tiles, whose steps are short; costs one
 // more set of staging registers).
 // EPI: 1 = the epilogue also takes BatchNormalization backward statistics (see dj_igemm_fast.h), input gradient only.
-template <int BM, int BN, int AM, int BMD, int PRO, int PREC, int BK = 32, int PF = 1, int EPI = 0>
+// AT, BT: storage type of A (and A2) / of B in HBM, see the header comment.
+template <int BM, int BN, int AM, int BMD, int PRO, int PREC, int BK = 32, int PF = 1, int EPI = 0, int AT = 0, int BT = 0>
 __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p) {
   static_assert(EPI == 0 || (AM == 1 && BMD == 1), "BatchNormalization backward statistics: input-gradient GEMM only");
+  static_assert(BT == 0 || BMD == 0, "the per-tap transposed B operand is the fp32 weight tensor");
+  constexpr int EA = AT ? 2 : 4, EB = BT ? 2 : 4;   // bytes per stored element
+  using ARaw = typename DjRaw<AT>::type;
+  using BRaw = typename DjRaw<BT>::type;
+  // the piece goes from HBM to LDS as it is: stored in the MFMA's type, no prologue
+  constexpr bool A_COPY = (AT == PREC) && PRO == 0, B_COPY = (BT == PREC);
   using Cfg = DjH16Cfg<BM, BN, AM, BMD, BK>;
   constexpr int TM = Cfg::TM, TN = Cfg::TN, NA = Cfg::NA, NB = Cfg::NB;
   constexpr int PA = Cfg::PA, PB = Cfg::PB, KCH = Cfg::KCH, RPP = Cfg::RPP;
@@ -133,7 +186,7 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
         int rw = (AM == 0) ? w * p.sW - p.pL : w + p.pL;
         a_rh[j] = rh;
         a_rw[j] = rw;
-        a_off[j] = ((img * p.srcH * p.srcW + rh * p.srcW + rw) * p.ldsrc + 4 * ac) * 4;
+        a_off[j] = ((img * p.srcH * p.srcW + rh * p.srcW + rw) * p.ldsrc + 4 * ac) * EA;
       } else {
         a_rh[j] = -(1 << 28);
         a_rw[j] = -(1 << 28);
@@ -164,7 +217,7 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       b_ok[j] = n < p.N;
-      b_off[j] = ((bkr0 + BKSTEP * j) * p.ldb + n) * 4;
+      b_off[j] = ((bkr0 + BKSTEP * j) * p.ldb + n) * EB;
     }
   } else {
 #pragma unroll
@@ -185,10 +238,12 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
 
   // one K-step's operands between the buffer loads and the LDS stores
   struct Regs {
-    f32x4 ra[NA], rb[NB];
+    ARaw ra[NA];
+    BRaw rb[NB];
     unsigned a_valid;
     f32x4 psc, psh;
-    f32x4 ra2[PRO == 3 ? NA : 1], psc2, psh2;
+    ARaw ra2[PRO == 3 ? NA : 1];
+    f32x4 psc2, psh2;
     int pro_c0;
   };
   Regs r0, r1;
@@ -198,15 +253,15 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
   r0.psh = r1.psh = r0.psh2 = r1.psh2 = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto issue_loads = [&](Regs& R, int kcur, bool live) {
-    f32x4(&ra)[NA] = R.ra;
-    f32x4(&rb)[NB] = R.rb;
-    f32x4(&ra2)[PRO == 3 ? NA : 1] = R.ra2;
+    ARaw(&ra)[NA] = R.ra;
+    BRaw(&rb)[NB] = R.rb;
+    ARaw(&ra2)[PRO == 3 ? NA : 1] = R.ra2;
     unsigned& a_valid = R.a_valid;
     f32x4 &psc = R.psc, &psh = R.psh, &psc2 = R.psc2, &psh2 = R.psh2;
     int& pro_c0 = R.pro_c0;
     if (AM != 2) {
       const int dh = t_kh * p.dH, dw = t_kw * p.dW;
-      const int delta = (AM == 0) ? ((dh * p.srcW + dw) * p.ldsrc + t_c0) * 4 : (-(dh * p.srcW + dw) * p.ldsrc + t_c0) * 4;
+      const int delta = (AM == 0) ? ((dh * p.srcW + dw) * p.ldsrc + t_c0) * EA : (-(dh * p.srcW + dw) * p.ldsrc + t_c0) * EA;
       if (PRO == 1) {
         psc = dj_buf_ld4(rS, (unsigned)(t_c0 + 4 * ac) * 4u);
         psh = dj_buf_ld4(rT, (unsigned)(t_c0 + 4 * ac) * 4u);
@@ -229,8 +284,8 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
         for (int j = 0; j < NA; ++j) {
           const bool ok = live && pm[j] >= 0;
           const unsigned m = (unsigned)pm[j];
-          ra[j] = dj_buf_ld4(rA, ok ? (__umul24(m, (unsigned)p.ldsrc) + cb) * 4u : DJ_OOB);
-          ra2[j] = dj_buf_ld4(rA2, ok ? (__umul24(m, (unsigned)p.ldsrc2) + cb) * 4u : DJ_OOB);
+          ra[j] = dj_buf_ldraw<AT>(rA, ok ? (__umul24(m, (unsigned)p.ldsrc) + cb) * (unsigned)EA : DJ_OOB);
+          ra2[j] = dj_buf_ldraw<AT>(rA2, ok ? (__umul24(m, (unsigned)p.ldsrc2) + cb) * (unsigned)EA : DJ_OOB);
           a_valid |= ok ? (1u << j) : 0u;
         }
       } else {
@@ -239,7 +294,7 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
         int h = (AM == 0) ? a_rh[j] + dh : a_rh[j] - dh;
         int w = (AM == 0) ? a_rw[j] + dw : a_rw[j] - dw;
         bool ok = live && (unsigned)h < (unsigned)p.srcH && (unsigned)w < (unsigned)p.srcW;
-        ra[j] = dj_buf_ld4(rA, ok ? (unsigned)(a_off[j] + delta) : DJ_OOB);
+        ra[j] = dj_buf_ldraw<AT>(rA, ok ? (unsigned)(a_off[j] + delta) : DJ_OOB);
         a_valid |= ok ? (1u << j) : 0u;
       }
       }
@@ -263,22 +318,22 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
       for (int i = 0; i < NA; ++i) {
         int h = h0 + a2_dh[i], w = w0 + a2_dw[i];
         bool ok = rowok && a2_ok[i] && (unsigned)h < (unsigned)p.srcH && (unsigned)w < (unsigned)p.srcW;
-        unsigned off = (unsigned)((pb + h * p.srcW + w) * p.ldsrc + a2_c[i]) * 4u;
-        ra[i] = dj_buf_ld4(rA, ok ? off : DJ_OOB);
+        unsigned off = (unsigned)((pb + h * p.srcW + w) * p.ldsrc + a2_c[i]) * (unsigned)EA;
+        ra[i] = dj_buf_ldraw<AT>(rA, ok ? off : DJ_OOB);
         a_valid |= ok ? (1u << i) : 0u;
       }
     }
     if (BMD == 0) {
-      const int base = kcur * p.ldb * 4;
+      const int base = kcur * p.ldb * EB;
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
         bool ok = live && b_ok[j] && (AM != 2 || kcur + bkr0 + BKSTEP * j < kend);
-        rb[j] = dj_buf_ld4(rB, ok ? (unsigned)(b_off[j] + base) : DJ_OOB);
+        rb[j] = dj_buf_ldraw<BT>(rB, ok ? (unsigned)(b_off[j] + base) : DJ_OOB);
       }
     } else {
       const unsigned base = (unsigned)(t_tap * p.bTapStride + t_c0) * 4u;
 #pragma unroll
-      for (int j = 0; j < NB; ++j) rb[j] = dj_buf_ld4(rB, (live && b_ok[j]) ? (unsigned)b_off[j] + base : DJ_OOB);
+      for (int j = 0; j < NB; ++j) rb[j] = dj_buf_ldraw<BT>(rB, (live && b_ok[j]) ? (unsigned)b_off[j] + base : DJ_OOB);
     }
     if (AM != 2 || BMD == 1) {
       t_c0 += BK;
@@ -294,39 +349,49 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
 
   // prologue in fp32, then ONE rounding per element, 8-byte LDS stores
   auto store_tiles = [&](const Regs& R, short* sA, short* sB) {
-    const f32x4(&ra)[NA] = R.ra;
-    const f32x4(&rb)[NB] = R.rb;
-    const f32x4(&ra2)[PRO == 3 ? NA : 1] = R.ra2;
+    const ARaw(&ra)[NA] = R.ra;
+    const BRaw(&rb)[NB] = R.rb;
+    const ARaw(&ra2)[PRO == 3 ? NA : 1] = R.ra2;
     const unsigned a_valid = R.a_valid;
     const f32x4 psc = R.psc, psh = R.psh, psc2 = R.psc2, psh2 = R.psh2;
     const int pro_c0 = R.pro_c0;
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-      f32x4 v = ra[j];
+      short* dst = (AM != 2) ? sA + (ar0 + ARPP * j) * PA + 4 * ac : sA + ar0 * PA + 4 * (ac + 8 * j);
+      if constexpr (A_COPY) {   // stored in the MFMA's type, no prologue: out-of-range pieces arrived as zeros
+        *reinterpret_cast<u32x2*>(dst) = ra[j];
+        continue;
+      }
+      f32x4 v = dj_raw_to_f32<AT>(ra[j]);
       if (PRO) {
         f32x4 sc = (AM == 2) ? a2_sc[j] : psc, sh = (AM == 2) ? a2_sh[j] : psh;
         v = v * sc + sh;
-        if (PRO == 3) v += ra2[j] * psc2 + psh2;
+        if (PRO == 3) v += dj_raw_to_f32<AT>(ra2[j]) * psc2 + psh2;
         bool ok = (a_valid >> j) & 1u;
         const float lo = ok ? relu_floor : 0.f, hi = ok ? INFINITY : 0.f;   // ReLU + out-of-bounds zero: one v_med3
         v.x = __builtin_amdgcn_fmed3f(v.x, lo, hi);
         v.y = __builtin_amdgcn_fmed3f(v.y, lo, hi);
         v.z = __builtin_amdgcn_fmed3f(v.z, lo, hi);
         v.w = __builtin_amdgcn_fmed3f(v.w, lo, hi);
-        if (PRO == 3 && store_sum)
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rY,
-                                                 ok ? (int)((__umul24((unsigned)pm[j], (unsigned)p.ld_sum) +
-                                                             (unsigned)(4 * ac + pro_c0)) * 4u)
-                                                    : (int)DJ_OOB,
-                                                 0, 0);
+        if (PRO == 3 && store_sum) {
+          // the Add + ReLU output for its other readers, in the type that tensor has in HBM (wave-uniform)
+          const unsigned e = __umul24((unsigned)pm[j], (unsigned)p.ld_sum) + (unsigned)(4 * ac + pro_c0);
+          if (p.sum_dt == 0)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rY, ok ? (int)(e * 4u) : (int)DJ_OOB, 0, 0);
+          else
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, p.sum_dt == 1 ? dj_round4<1>(v) : dj_round4<2>(v)),
+                                                  rY, ok ? (int)(e * 2u) : (int)DJ_OOB, 0, 0);
+        }
       }
-      short* dst = (AM != 2) ? sA + (ar0 + ARPP * j) * PA + 4 * ac : sA + ar0 * PA + 4 * (ac + 8 * j);
       *reinterpret_cast<dj_short4*>(dst) = dj_round4<PREC>(v);
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       short* dst = (BMD == 0) ? sB + (bkr0 + BKSTEP * j) * PB + 4 * bcn : sB + (br0 + RPP * j) * PB + 4 * bc;
-      *reinterpret_cast<dj_short4*>(dst) = dj_round4<PREC>(rb[j]);
+      if constexpr (B_COPY)
+        *reinterpret_cast<u32x2*>(dst) = rb[j];
+      else
+        *reinterpret_cast<dj_short4*>(dst) = dj_round4<PREC>(dj_raw_to_f32<BT>(rb[j]));
     }
   };
 
@@ -400,5 +465,5 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
   } else {
     for (int kt = 0; kt < nk; ++kt) kstep(r0, r0, kt, kbeg + (kt + 1) * BK, kt + 1 < nk);
   }
-  dj_igemm_epilogue<BM, BN, 2, 2, EPI == 1>(p, acc, smem_base, tile_m, m0, n0, ky);
+  dj_igemm_epilogue<BM, BN, 2, 2, EPI == 1, true>(p, acc, smem_base, tile_m, m0, n0, ky);
 }

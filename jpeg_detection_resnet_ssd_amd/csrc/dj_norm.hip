@@ -586,6 +586,280 @@ extern "C" int dj_relu_bwd(const float* dy, int ld_dy, const float* y, int ld_y,
   return DJ_OK;
 }
 
+// ---------------------------------------------------------------------------------
+// The same elementwise passes over tensors that carry their storage type (round 3, BASELINE config 5: activations held as
+// fp16 and their gradients as bf16 in HBM inside the backbone, fp32 elsewhere): every tensor operand comes with a type
+// code (DJ_F32 / DJ_F16 / DJ_BF16), looked at per access with a wave-uniform branch -- these passes are HBM-bound, the
+// branch is free -- and all arithmetic stays fp32.  A 4-element piece of a 16-bit tensor is one 8-byte access.
+// ---------------------------------------------------------------------------------
+typedef unsigned int dj_u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 dj_h4 __attribute__((ext_vector_type(4)));
+
+template <int VEC>
+__device__ __forceinline__ f32x4 dj_ldt(const void* base, long idx, int dt) {
+  if (dt == DJ_F32) return VecIO<VEC>::ld(reinterpret_cast<const float*>(base) + idx);
+  if (VEC == 4) {
+    const dj_u32x2 v = *reinterpret_cast<const dj_u32x2*>(reinterpret_cast<const unsigned short*>(base) + idx);
+    if (dt == DJ_F16) {
+      const dj_h4 h = __builtin_bit_cast(dj_h4, v);
+      return f32x4{(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+    }
+    return f32x4{__builtin_bit_cast(float, v.x << 16), __builtin_bit_cast(float, v.x & 0xFFFF0000u),
+                 __builtin_bit_cast(float, v.y << 16), __builtin_bit_cast(float, v.y & 0xFFFF0000u)};
+  }
+  const unsigned short u = reinterpret_cast<const unsigned short*>(base)[idx];
+  const float f = (dt == DJ_F16) ? (float)__builtin_bit_cast(_Float16, u) : __builtin_bit_cast(float, (unsigned)u << 16);
+  return f32x4{f, 0.f, 0.f, 0.f};
+}
+
+__device__ __forceinline__ unsigned dj_pack2(float lo, float hi, int dt) {
+  if (dt == DJ_F16) {
+    const _Float16 a = (_Float16)lo, b = (_Float16)hi;
+    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+  }
+  const __bf16 a = (__bf16)lo, b = (__bf16)hi;   // round to nearest even
+  return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+template <int VEC>
+__device__ __forceinline__ void dj_stt(void* base, long idx, int dt, f32x4 v) {
+  if (dt == DJ_F32) {
+    VecIO<VEC>::st(reinterpret_cast<float*>(base) + idx, v);
+  } else if (VEC == 4) {
+    *reinterpret_cast<dj_u32x2*>(reinterpret_cast<unsigned short*>(base) + idx) = dj_u32x2{dj_pack2(v.x, v.y, dt), dj_pack2(v.z, v.w, dt)};
+  } else {
+    reinterpret_cast<unsigned short*>(base)[idx] = (unsigned short)(dj_pack2(v.x, 0.f, dt) & 0xFFFFu);
+  }
+}
+
+static inline bool dt_known(int dt) { return dt == DJ_F32 || dt == DJ_F16 || dt == DJ_BF16; }
+// 4-element pieces legal: 16-byte aligned base (8 would do for 16-bit) and a pixel stride that is a multiple of 4 elements
+static inline bool vec_ok(const void* p, long ld) { return al16(p) && ld % 4 == 0; }
+
+template <int VEC>
+__global__ __launch_bounds__(256) void dj_affine_act_t_kernel(const void* x, int dt_x, int ldx, const float* scale,
+                                                               const float* shift, const void* res, int dt_res, int ldres,
+                                                               const float* rscale, const float* rshift, void* y, int dt_y,
+                                                               int ldy, long rows, int C, int relu) {
+  using IO = VecIO<VEC>;
+  const int cv = C / VEC;
+  long total = rows * cv;
+  const float floor_ = relu ? 0.f : -INFINITY;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i / cv;
+    int c = (int)(i - r * cv) * VEC;
+    f32x4 v = dj_ldt<VEC>(x, r * ldx + c, dt_x);
+    if (scale) v = v * IO::ld(scale + c) + IO::ld(shift + c);
+    if (res) {
+      f32x4 t = dj_ldt<VEC>(res, r * ldres + c, dt_res);
+      if (rscale) t = t * IO::ld(rscale + c) + IO::ld(rshift + c);
+      v += t;
+    }
+    v.x = fmaxf(v.x, floor_);
+    v.y = fmaxf(v.y, floor_);
+    v.z = fmaxf(v.z, floor_);
+    v.w = fmaxf(v.w, floor_);
+    dj_stt<VEC>(y, r * ldy + c, dt_y, v);
+  }
+}
+
+extern "C" int dj_affine_act_t(const void* x, int dt_x, int ldx, const float* scale, const float* shift, const void* res,
+                               int dt_res, int ldres, const float* res_scale, const float* res_shift, void* y, int dt_y,
+                               int ldy, long rows, int C, int relu, void* stream) {
+  DJ_CHECK_ARG(x && y && rows > 0 && C > 0 && ldx >= C && ldy >= C, "affine_act: bad arguments");
+  DJ_CHECK_ARG(dt_known(dt_x) && dt_known(dt_y) && (!res || dt_known(dt_res)), "affine_act: unknown storage type");
+  DJ_CHECK_ARG((scale == nullptr) == (shift == nullptr) && (res_scale == nullptr) == (res_shift == nullptr),
+               "affine_act: scale/shift come together");
+  DJ_CHECK_ARG(res || !res_scale, "affine_act: res_scale without res");
+  hipStream_t s = (hipStream_t)stream;
+  bool v4 = (C % 4 == 0) && vec_ok(x, ldx) && vec_ok(y, ldy) && (!res || vec_ok(res, ldres)) && al16(scale) && al16(shift) &&
+            al16(res_scale) && al16(res_shift);
+  if (v4)
+    hipLaunchKernelGGL(dj_affine_act_t_kernel<4>, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, s, x, dt_x, ldx, scale, shift,
+                       res, dt_res, ldres, res_scale, res_shift, y, dt_y, ldy, rows, C, relu);
+  else
+    hipLaunchKernelGGL(dj_affine_act_t_kernel<1>, dim3(ew_blocks(rows * C)), dim3(256), 0, s, x, dt_x, ldx, scale, shift, res,
+                       dt_res, ldres, res_scale, res_shift, y, dt_y, ldy, rows, C, relu);
+  DJ_CHECK_LAUNCH("dj_affine_act_t");
+  return DJ_OK;
+}
+
+// BnBwdF over typed tensors
+struct BnBwdTF {
+  const void* dy;
+  int dt_dy, ld_dy;
+  const void* z;
+  int dt_z, ld_z;
+  const void* y;
+  int dt_y, ld_y;
+  const float* mean;
+  const float* invstd;
+  const float* scale;
+  const float* shift;
+  int mask_mode;
+  template <int VEC>
+  __device__ __forceinline__ void eval(long r, int c, f32x4& v0, f32x4& v1) const {
+    using IO = VecIO<VEC>;
+    f32x4 g = dj_ldt<VEC>(dy, r * ld_dy + c, dt_dy);
+    f32x4 zz = dj_ldt<VEC>(z, r * ld_z + c, dt_z);
+    f32x4 m = {1.f, 1.f, 1.f, 1.f};
+    if (mask_mode == 1)
+      m = dj_ldt<VEC>(y, r * ld_y + c, dt_y);
+    else if (mask_mode == 2)
+      m = zz * IO::ld(scale + c) + IO::ld(shift + c);
+    g.x = (m.x > 0.f) ? g.x : 0.f;
+    g.y = (m.y > 0.f) ? g.y : 0.f;
+    g.z = (m.z > 0.f) ? g.z : 0.f;
+    g.w = (m.w > 0.f) ? g.w : 0.f;
+    v0 = g;
+    v1 = g * (zz - IO::ld(mean + c)) * IO::ld(invstd + c);
+  }
+};
+
+extern "C" int dj_bn_bwd_reduce_t(const void* dy, int dt_dy, int ld_dy, const void* z, int dt_z, int ld_z, const void* y,
+                                  int dt_y, int ld_y, const float* mean, const float* invstd, const float* scale,
+                                  const float* shift, int mask_mode, long rows, int C, float* partial, void* stream) {
+  DJ_CHECK_ARG(dy && z && mean && invstd && partial && rows > 0 && C > 0, "bn_bwd_reduce: bad arguments");
+  DJ_CHECK_ARG(dt_known(dt_dy) && dt_known(dt_z) && (mask_mode != 1 || dt_known(dt_y)), "bn_bwd_reduce: unknown storage type");
+  DJ_CHECK_ARG(mask_mode >= 0 && mask_mode <= 2, "bn_bwd_reduce: mask_mode");
+  DJ_CHECK_ARG(mask_mode != 1 || y, "bn_bwd_reduce: mask_mode 1 needs y");
+  DJ_CHECK_ARG(mask_mode != 2 || (scale && shift), "bn_bwd_reduce: mask_mode 2 needs scale/shift");
+  BnBwdTF f{dy, dt_dy, ld_dy, z, dt_z, ld_z, y, dt_y, ld_y, mean, invstd, scale, shift, mask_mode};
+  bool v4 = C % 4 == 0 && vec_ok(dy, ld_dy) && vec_ok(z, ld_z) && (mask_mode != 1 || vec_ok(y, ld_y)) && al16p(mean) &&
+            al16p(invstd) && al16p(scale) && al16p(shift) && al16p(partial);
+  return launch_colreduce(f, rows, C, v4, partial, (hipStream_t)stream, "dj_bn_bwd_reduce_t");
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void dj_bn_bwd_apply_t_kernel(const void* dy, int dt_dy, int ld_dy, const void* z, int dt_z,
+                                                                 int ld_z, const void* y, int dt_y, int ld_y,
+                                                                 const float* scale, const float* shift, int mask_mode,
+                                                                 const float* k0, const float* k1, const float* k2, void* dz,
+                                                                 int dt_dz, int ld_dz, long rows, int C, void* dmasked,
+                                                                 int dt_dm, int ld_dm, int dm_beta) {
+  using IO = VecIO<VEC>;
+  const int cv = C / VEC;
+  long total = rows * cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i / cv;
+    int c = (int)(i - r * cv) * VEC;
+    f32x4 g = dj_ldt<VEC>(dy, r * ld_dy + c, dt_dy);
+    f32x4 zz = dj_ldt<VEC>(z, r * ld_z + c, dt_z);
+    f32x4 m = {1.f, 1.f, 1.f, 1.f};
+    if (mask_mode == 1) {
+      m = dj_ldt<VEC>(y, r * ld_y + c, dt_y);
+    } else if (mask_mode == 2) {
+      m = zz * IO::ld(scale + c) + IO::ld(shift + c);
+    }
+    g.x = (m.x > 0.f) ? g.x : 0.f;
+    g.y = (m.y > 0.f) ? g.y : 0.f;
+    g.z = (m.z > 0.f) ? g.z : 0.f;
+    g.w = (m.w > 0.f) ? g.w : 0.f;
+    dj_stt<VEC>(dz, r * ld_dz + c, dt_dz, IO::ld(k0 + c) * g + IO::ld(k1 + c) * zz + IO::ld(k2 + c));
+    if (dmasked) {   // the masked upstream gradient is also the identity shortcut's gradient (Add + ReLU backward)
+      const long o = r * ld_dm + c;
+      dj_stt<VEC>(dmasked, o, dt_dm, dm_beta ? g + dj_ldt<VEC>(dmasked, o, dt_dm) : g);
+    }
+  }
+}
+
+extern "C" int dj_bn_bwd_apply_t(const void* dy, int dt_dy, int ld_dy, const void* z, int dt_z, int ld_z, const void* y,
+                                 int dt_y, int ld_y, const float* scale, const float* shift, int mask_mode, const float* k0,
+                                 const float* k1, const float* k2, void* dz, int dt_dz, int ld_dz, long rows, int C,
+                                 void* dmasked, int dt_dm, int ld_dm, int dm_beta, void* stream) {
+  DJ_CHECK_ARG(dy && z && k0 && k1 && k2 && dz && rows > 0 && C > 0, "bn_bwd_apply: bad arguments");
+  DJ_CHECK_ARG(dt_known(dt_dy) && dt_known(dt_z) && dt_known(dt_dz) && (mask_mode != 1 || dt_known(dt_y)) &&
+                   (!dmasked || dt_known(dt_dm)),
+               "bn_bwd_apply: unknown storage type");
+  DJ_CHECK_ARG(!dmasked || ld_dm >= C, "bn_bwd_apply: ld_dm < C");
+  DJ_CHECK_ARG(mask_mode >= 0 && mask_mode <= 2, "bn_bwd_apply: mask_mode");
+  DJ_CHECK_ARG(mask_mode != 1 || y, "bn_bwd_apply: mask_mode 1 needs y");
+  DJ_CHECK_ARG(mask_mode != 2 || (scale && shift), "bn_bwd_apply: mask_mode 2 needs scale/shift");
+  hipStream_t s = (hipStream_t)stream;
+  bool v4 = (C % 4 == 0) && vec_ok(dy, ld_dy) && vec_ok(z, ld_z) && vec_ok(dz, ld_dz) && (mask_mode != 1 || vec_ok(y, ld_y)) &&
+            al16(scale) && al16(shift) && al16(k0) && al16(k1) && al16(k2) && (!dmasked || vec_ok(dmasked, ld_dm));
+  if (v4)
+    hipLaunchKernelGGL(dj_bn_bwd_apply_t_kernel<4>, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, s, dy, dt_dy, ld_dy, z, dt_z,
+                       ld_z, y, dt_y, ld_y, scale, shift, mask_mode, k0, k1, k2, dz, dt_dz, ld_dz, rows, C, dmasked, dt_dm,
+                       ld_dm, dm_beta);
+  else
+    hipLaunchKernelGGL(dj_bn_bwd_apply_t_kernel<1>, dim3(ew_blocks(rows * C)), dim3(256), 0, s, dy, dt_dy, ld_dy, z, dt_z, ld_z,
+                       y, dt_y, ld_y, scale, shift, mask_mode, k0, k1, k2, dz, dt_dz, ld_dz, rows, C, dmasked, dt_dm, ld_dm,
+                       dm_beta);
+  DJ_CHECK_LAUNCH("dj_bn_bwd_apply_t");
+  return DJ_OK;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void dj_relu_bwd_t_kernel(const void* dy, int dt_dy, int ld_dy, const void* y, int dt_y,
+                                                             int ld_y, void* dx, int dt_dx, int ld_dx, long rows, int C,
+                                                             int beta) {
+  const int cv = C / VEC;
+  long total = rows * cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i / cv;
+    int c = (int)(i - r * cv) * VEC;
+    f32x4 g = dj_ldt<VEC>(dy, r * ld_dy + c, dt_dy);
+    f32x4 m = dj_ldt<VEC>(y, r * ld_y + c, dt_y);
+    g.x = (m.x > 0.f) ? g.x : 0.f;
+    g.y = (m.y > 0.f) ? g.y : 0.f;
+    g.z = (m.z > 0.f) ? g.z : 0.f;
+    g.w = (m.w > 0.f) ? g.w : 0.f;
+    const long o = r * ld_dx + c;
+    if (beta) g += dj_ldt<VEC>(dx, o, dt_dx);
+    dj_stt<VEC>(dx, o, dt_dx, g);
+  }
+}
+
+extern "C" int dj_relu_bwd_t(const void* dy, int dt_dy, int ld_dy, const void* y, int dt_y, int ld_y, void* dx, int dt_dx,
+                             int ld_dx, long rows, int C, int beta, void* stream) {
+  DJ_CHECK_ARG(dy && y && dx && rows > 0 && C > 0, "relu_bwd: bad arguments");
+  DJ_CHECK_ARG(dt_known(dt_dy) && dt_known(dt_y) && dt_known(dt_dx), "relu_bwd: unknown storage type");
+  hipStream_t s = (hipStream_t)stream;
+  bool v4 = (C % 4 == 0) && vec_ok(dy, ld_dy) && vec_ok(y, ld_y) && vec_ok(dx, ld_dx);
+  if (v4)
+    hipLaunchKernelGGL(dj_relu_bwd_t_kernel<4>, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, s, dy, dt_dy, ld_dy, y, dt_y,
+                       ld_y, dx, dt_dx, ld_dx, rows, C, beta);
+  else
+    hipLaunchKernelGGL(dj_relu_bwd_t_kernel<1>, dim3(ew_blocks(rows * C)), dim3(256), 0, s, dy, dt_dy, ld_dy, y, dt_y, ld_y, dx,
+                       dt_dx, ld_dx, rows, C, beta);
+  DJ_CHECK_LAUNCH("dj_relu_bwd_t");
+  return DJ_OK;
+}
+
+// dst[r][c] (+)= src[r][c] with a change of storage type on the way (a 16-bit backbone tensor handed to a layer that
+// works on fp32, the gradient coming back)
+template <int VEC>
+__global__ __launch_bounds__(256) void dj_copy2d_t_kernel(const void* src, int dt_src, long lds, void* dst, int dt_dst,
+                                                           long ldd, long rows, long cols, int beta) {
+  const long cv = cols / VEC;
+  long total = rows * cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i / cv;
+    long c = (i - r * cv) * VEC;
+    f32x4 v = dj_ldt<VEC>(src, r * lds + c, dt_src);
+    const long o = r * ldd + c;
+    if (beta) v += dj_ldt<VEC>(dst, o, dt_dst);
+    dj_stt<VEC>(dst, o, dt_dst, v);
+  }
+}
+
+extern "C" int dj_copy2d_t(const void* src, int dt_src, long ld_src, void* dst, int dt_dst, long ld_dst, long rows, long cols,
+                           int beta, void* stream) {
+  DJ_CHECK_ARG(src && dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= cols, "copy2d: bad arguments");
+  DJ_CHECK_ARG(dt_known(dt_src) && dt_known(dt_dst), "copy2d: unknown storage type");
+  hipStream_t s = (hipStream_t)stream;
+  bool v4 = (cols % 4 == 0) && vec_ok(src, ld_src) && vec_ok(dst, ld_dst);
+  if (v4)
+    hipLaunchKernelGGL(dj_copy2d_t_kernel<4>, dim3(ew_blocks(rows * (cols / 4))), dim3(256), 0, s, src, dt_src, ld_src, dst,
+                       dt_dst, ld_dst, rows, cols, beta);
+  else
+    hipLaunchKernelGGL(dj_copy2d_t_kernel<1>, dim3(ew_blocks(rows * cols)), dim3(256), 0, s, src, dt_src, ld_src, dst, dt_dst,
+                       ld_dst, rows, cols, beta);
+  DJ_CHECK_LAUNCH("dj_copy2d_t");
+  return DJ_OK;
+}
+
 // dst[r][c] (+)= src[r][c]   (Concatenate / its gradient / Reshape+Concatenate(axis=1))
 template <int VEC>
 __global__ __launch_bounds__(256) void dj_copy2d_kernel(const float* src, long lds, float* dst, long ldd, long rows,

@@ -316,6 +316,13 @@ class Plan(object):
         # the arithmetic mode this plan was lowered under (K.set_floatx at that time): its launches run in it whatever the
         # process default or another plan's mode is by then (per-thread override of the C library)
         self.compute_mode = int(_lib.load().dj_get_compute_mode()) if device.type == "cuda" else 0
+        # BASELINE config 5 proper (K.set_floatx('float16')): conv outputs and block sums of the backbone are held as fp16
+        # in HBM, their gradients as bf16 (the layers decide per tensor, keras/layers.py `_takes16`); DJ_STORE16=0 keeps
+        # every tensor fp32 as in round 2.  Tensors with fewer rows than DJ_STORE16_MIN_ROWS stay fp32: they carry no
+        # traffic worth halving, and their GEMMs are the ones that want to split their reduction over workgroups, which a
+        # 16-bit result cannot take (no atomics, no slabs)
+        self.store16 = self.compute_mode == 1 and os.environ.get("DJ_STORE16", "1") != "0"
+        self.store16_min_rows = int(os.environ.get("DJ_STORE16_MIN_ROWS", "8192"))
         self.grads_cleared = False   # True: the first backward launch zeroes the model's whole flat gradient buffer
         # weight-gradient GEMMs only feed the optimizer, so they run on a second HIP stream and fill the CUs the
         # data-gradient chain leaves idle at its tile-quantisation tails (DJ_SIDE_WGRAD=0 keeps one stream)
@@ -337,18 +344,32 @@ class Plan(object):
             self._join_event = None
 
     # ---- allocation -------------------------------------------------------------
-    def empty(self, *shape):
-        t = torch.empty(*shape, dtype=torch.float32, device=self.device)
-        self.bytes_allocated += t.numel() * 4
+    def empty(self, *shape, dtype=torch.float32):
+        t = torch.empty(*shape, dtype=dtype, device=self.device)
+        self.bytes_allocated += t.numel() * t.element_size()
         return t
 
-    def zeroed_each_step(self, *shape):
+    def act_dtype(self, rows, channels):
+        """Storage type of a backbone activation with this many rows / channels (the caller has checked that every layer
+        that touches it can work on 16-bit tensors)."""
+        if self.store16 and rows >= self.store16_min_rows and channels % 32 == 0:
+            return torch.float16
+        return torch.float32
+
+    @staticmethod
+    def grad_dtype(buf):
+        """Gradients of 16-bit activations are held as bf16 (they need the exponent range), everything else as fp32."""
+        return torch.float32 if buf.dtype == torch.float32 else torch.bfloat16
+
+    def zeroed_each_step(self, *shape, dtype=torch.float32):
         """A buffer out of an arena that ONE memset clears at the start of every step: for gradient tensors whose first
         writer accumulates with atomics (split-K) or scatters (stride-2 1x1 dgrad) and would otherwise need its own
         memset launch in the middle of the backward chain."""
-        n = 1
+        n_el = 1
         for d in shape:
-            n *= int(d)
+            n_el *= int(d)
+        es = torch.empty(0, dtype=dtype).element_size()
+        n = (n_el * es + 3) // 4          # floats of the arena that hold the tensor
         n_pad = (n + 63) // 64 * 64
         chunk = 64 << 20     # floats per arena chunk (256 MB)
         if not self._arena or self._arena_used + n_pad > self._arena[-1].numel():
@@ -357,7 +378,8 @@ class Plan(object):
             self.bytes_allocated += self._arena[-1].numel() * 4
             if len(self._arena) == 1:
                 self.fwd.insert(0, self._clear_arena)
-        t = self._arena[-1][self._arena_used:self._arena_used + n].view(*shape)
+        t = self._arena[-1][self._arena_used:self._arena_used + n]
+        t = t.view(*shape) if dtype == torch.float32 else t.view(dtype)[:n_el].view(*shape)
         self._arena_used += n_pad
         self._arena_high[len(self._arena) - 1] = self._arena_used
         return t
@@ -601,10 +623,11 @@ class Plan(object):
             buf, beta = self.grad_of(v.alias_of, zeroed)
             return v.alias_view(buf), beta
         if v.grad is None:
+            gdt = self.grad_dtype(v.buf)
             if zeroed:
-                v.grad = GradRef(self.zeroed_each_step(*v.buf.shape))
+                v.grad = GradRef(self.zeroed_each_step(*v.buf.shape, dtype=gdt))
                 return v.grad.buf, 1
-            v.grad = GradRef(self.empty(*v.buf.shape))
+            v.grad = GradRef(self.empty(*v.buf.shape, dtype=gdt))
             return v.grad.buf, 0
         assert v.grad.mask_y is None, "cannot accumulate into a masked gradient reference"
         return v.grad.buf, 1

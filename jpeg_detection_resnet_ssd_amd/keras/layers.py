@@ -203,7 +203,8 @@ def _materialised(v, who, plan=None, allow_pad=False):
         rows, c, ld = rows_of(src.buf)
         y = plan.empty(*src.buf.shape)
         zbuf, sc, sh, relu = src.buf, src.scale, src.shift, int(src.relu)
-        plan.emit(lambda: call("dj_affine_act", zbuf, ld, sc, sh, None, 0, None, None, y, c, rows, c, relu))
+        args = Kn.affine_act_call(zbuf, ld, sc, sh, None, 0, None, None, y, c, rows, c, relu)
+        plan.emit(lambda: call(*args))
         src._mat = y
     return src._mat
 
@@ -225,6 +226,32 @@ def _bias_grad(plan, dy, spec):
 # =====================================================================================
 # Conv2D / Conv2DTranspose / Dense
 # =====================================================================================
+def _takes16(model, t):
+    """Every reader of Keras tensor `t` can work on a tensor held in 16 bits and write its bf16 gradient: Conv2D layers
+    whose three GEMMs take the branch-free reduced-precision kernels, BatchNormalization behind a convolution, Add, and
+    Activation('relu') in front of such layers (BASELINE config 5: the conv -> BN -> ReLU -> conv chains and the residual
+    sums of the bottleneck blocks, localisation_part/models/keras_ssd300_dct_j2d_resnet.py:46-164).  Everything else
+    (L2Normalization, pooling, Concatenate, the predictor heads, model outputs) keeps its input in fp32."""
+    users = model.consumers_of(t)
+    if not users or any(t is o for o in model.outputs):
+        return False
+    for u in users:
+        if isinstance(u, Activation):
+            if u.activation != "relu" or not _takes16(model, u.outbound[0]):
+                return False
+        elif isinstance(u, BatchNormalization):
+            if type(t.layer) is not Conv2D:      # its statistics come from the producing convolution's epilogue
+                return False
+        elif isinstance(u, Add):
+            continue
+        elif type(u) is Conv2D:
+            if not u.accepts16(t.shape[-1]):
+                return False
+        else:
+            return False
+    return True
+
+
 def _bn_backward_fusable(plan, model, layer, x):
     """-> the BatchNormalization Value whose backward statistics the input-gradient GEMM of `layer` may take (its input `x`
     is that layer's output, optionally behind Activation('relu'), and `layer` is the only reader), else None.
@@ -277,6 +304,16 @@ class Conv2D(Layer):
         _, h, w, _ = input_shape
         _, _, oh, ow = Kn.conv_geometry(h, w, self.kernel_size, self.strides, self.padding, self.dilation_rate)
         return (input_shape[0], oh, ow, self.filters)
+
+    def accepts16(self, in_c):
+        """This layer can read a fp16 input with `in_c` channels and write its bf16 gradient: forward, weight gradient and
+        input gradient all take the branch-free reduced-precision kernels (csrc/dj_conv.hip: channels that are multiples of
+        32, and an input gradient that is stride 1 or the strided 1x1 scatter form)."""
+        if in_c % 32 or self.filters % 32:
+            return False
+        if self.strides != (1, 1) and (self.kernel_size != (1, 1) or self.strides[0] != self.strides[1]):
+            return False
+        return True
 
     def _fusable_siblings(self, model, x):
         """The Conv2D layers that read the same tensor with the same geometry and feed neither an activation nor a
@@ -441,7 +478,16 @@ class Conv2D(Layer):
                 stats = plan.empty(nrows, 2, self.filters)
         # a split-K forward (the small-M layers) leaves its partial tiles in the plan's workspace and a fixed-order
         # reduction writes y (and takes the statistics of a `split_instead` launch): bit-reproducible, no cleared y
-        y = plan.empty(b, desc.out_h, desc.out_w, self.filters)
+        # Raw output in fp16 (config 5 proper) when it feeds nothing but a BatchNormalization whose readers take 16-bit
+        # tensors and this layer's own gradient GEMMs can read the bf16 gradient that comes back
+        y_dtype = torch.float32
+        if (plan.store16 and len(consumers) == 1 and isinstance(consumers[0], BatchNormalization) and not relu
+                and not split_instead and fused_bn is None and self.accepts16(cin)
+                and _takes16(model, consumers[0].outbound[0])):
+            y_dtype = plan.act_dtype(b * desc.out_h * desc.out_w, self.filters)
+        if x.buf.dtype != torch.float32 and not self.accepts16(cin):
+            raise NotImplementedError("%s cannot read a 16-bit input (lowering bug: _takes16 said it could)" % self.name)
+        y = plan.empty(b, desc.out_h, desc.out_w, self.filters, dtype=y_dtype)
         ws = plan.conv_workspace(desc, stats_may_split=split_instead)
         xbuf = x.buf
         pend = getattr(x, "pending_add", None)
@@ -724,6 +770,7 @@ class BatchNormalization(Layer):
             if x.conv_stats is not None:
                 partial, nrows, conv_bias = x.conv_stats
             else:
+                assert z.dtype == torch.float32, "BatchNormalization statistics of a 16-bit tensor come from its producer"
                 nrows = query("dj_reduce_rows", rows)
                 partial, conv_bias = plan.empty(nrows, 2, c), None
                 plan.emit(lambda: call("dj_colstats_partial", z, rows, c, ld, partial))
@@ -758,8 +805,8 @@ class BatchNormalization(Layer):
             else:
                 nr = query("dj_reduce_rows", rows)
                 part = plan.empty(nr, 2, c)
-                plan.emit_bwd(lambda: call("dj_bn_bwd_reduce", dy, ld_dy, z, ld, mask_y, ld_y, mean, invstd, scale, shift,
-                                           mode, rows, c, part))
+                red = Kn.bn_bwd_reduce_call(dy, ld_dy, z, ld, mask_y, ld_y, mean, invstd, scale, shift, mode, rows, c, part)
+                plan.emit_bwd(lambda: call(*red))
             plan.emit_bwd(lambda: call("dj_bn_bwd_finalize", part, nr, rows, gamma, mean, invstd, dgamma, dbeta, k0,
                                        k1, k2, c))
             plan.note_grad(self.gamma)
@@ -772,12 +819,13 @@ class BatchNormalization(Layer):
                 ld_dz = rows_of(dz)[2]
                 dm, dm_beta = also if also is not None else (None, 0)
                 ld_dm = rows_of(dm)[2] if dm is not None else 0
-                plan.emit_bwd(lambda: call("dj_bn_bwd_apply", dy, ld_dy, z, ld, mask_y, ld_y, scale, shift, mode, k0,
-                                           k1, k2, dz, ld_dz, rows, c, dm, ld_dm, int(dm_beta)))
+                app = Kn.bn_bwd_apply_call(dy, ld_dy, z, ld, mask_y, ld_y, scale, shift, mode, k0, k1, k2, dz, ld_dz, rows, c,
+                                           dm, ld_dm, int(dm_beta))
+                plan.emit_bwd(lambda: call(*app))
             elif also is not None:   # nothing to apply here: the shortcut still needs its masked gradient
                 dm, dm_beta = also
-                plan.emit_bwd(lambda: call("dj_relu_bwd", dy, ld_dy, mask_y, ld_y, dm, rows_of(dm)[2], rows, c,
-                                           int(dm_beta)))
+                rb = Kn.relu_bwd_call(dy, ld_dy, mask_y, ld_y, dm, rows_of(dm)[2], rows, c, int(dm_beta))
+                plan.emit_bwd(lambda: call(*rb))
 
         plan.on_backward(build_backward)
         return out
@@ -807,7 +855,8 @@ class Activation(Layer):
         xbuf = _materialised(x, self.name, plan)
         rows, c, ld = rows_of(xbuf)
         y = plan.empty(*xbuf.shape)
-        plan.emit(lambda: call("dj_affine_act", xbuf, ld, None, None, None, 0, None, None, y, c, rows, c, 1))
+        act = Kn.affine_act_call(xbuf, ld, None, None, None, 0, None, None, y, c, rows, c, 1)
+        plan.emit(lambda: call(*act))
         out = Value(y, needs_grad=x.needs_grad, name=self.name)
 
         def build_backward():
@@ -815,7 +864,8 @@ class Activation(Layer):
                 return
             dy = out.grad.buf
             dx, beta = plan.grad_of(x)
-            plan.emit_bwd(lambda: call("dj_relu_bwd", dy, rows_of(dy)[2], y, c, dx, rows_of(dx)[2], rows, c, beta))
+            rb = Kn.relu_bwd_call(dy, rows_of(dy)[2], y, c, dx, rows_of(dx)[2], rows, c, beta)
+            plan.emit_bwd(lambda: call(*rb))
 
         plan.on_backward(build_backward)
         return out
@@ -830,11 +880,13 @@ class Add(Layer):
         return input_shape[0]
 
     @staticmethod
-    def _first_consumer_conv(plan, model, relu_layer, a, y):
+    def _first_consumer_conv(plan, model, relu_layer, a, y, b=None):
         """The layer that runs first among the consumers of relu(Add) if it can take the sum as a fused prologue."""
         if os.environ.get("DJ_FUSE_ADD", "1") == "0" or relu_layer is None or not a.is_affine:
             return None
         if not (a.buf.is_contiguous() and y.dim() == 4):
+            return None
+        if b is not None and a.buf.dtype != b.buf.dtype:      # the fused prologue reads both operands in one storage type
             return None
         users = model.consumers_of(relu_layer.outbound[0])
         if not users:
@@ -860,18 +912,20 @@ class Add(Layer):
             consumers[0].absorbed = True
         rows, c, lda = rows_of(a.buf)
         ldb = rows_of(b.buf)[2]
-        y = plan.empty(*a.buf.shape)
+        # the block sum in fp16 (config 5 proper) when everybody who reads it takes 16-bit tensors
+        y_dtype = plan.act_dtype(rows, c) if (plan.store16 and _takes16(model, self.outbound[0])) else torch.float32
+        y = plan.empty(*a.buf.shape, dtype=y_dtype)
         abuf, bbuf = a.buf, b.buf
         out = Value(y, needs_grad=a.needs_grad or b.needs_grad, name=self.name)
-        first = self._first_consumer_conv(plan, model, consumers[0] if relu else None, a, y) if relu else None
+        first = self._first_consumer_conv(plan, model, consumers[0] if relu else None, a, y, b) if relu else None
         if first is not None:
             # no launch here: `first` (the next block's 1x1 conv) computes relu(bn(a) + b) in its A-tile prologue and
             # stores it to y (dj_conv2d_nhwc_fwd_addrelu) -- one elementwise pass and one read of y less per block
             out.pending_add = dict(consumer=first, z=abuf, z_scale=a.scale, z_shift=a.shift, res=bbuf, res_scale=b.scale,
                                    res_shift=b.shift)
         else:
-            plan.emit(lambda: call("dj_affine_act", abuf, lda, a.scale, a.shift, bbuf, ldb, b.scale, b.shift, y, c, rows,
-                                   c, int(relu)))
+            act = Kn.affine_act_call(abuf, lda, a.scale, a.shift, bbuf, ldb, b.scale, b.shift, y, c, rows, c, int(relu))
+            plan.emit(lambda: call(*act))
 
         def build_backward():
             if out.grad is None:
@@ -893,11 +947,10 @@ class Add(Layer):
                 else:
                     dv, beta = plan.grad_of(v)
                     if relu:
-                        plan.emit_bwd(lambda dv=dv, beta=beta: call("dj_relu_bwd", dy, c, y, c, dv, rows_of(dv)[2], rows,
-                                                                    c, beta))
+                        bw = Kn.relu_bwd_call(dy, c, y, c, dv, rows_of(dv)[2], rows, c, beta)
                     else:
-                        plan.emit_bwd(lambda dv=dv, beta=beta: call("dj_copy2d", dy, c, dv, rows_of(dv)[2], rows, c,
-                                                                    beta))
+                        bw = Kn.copy2d_call(dy, c, dv, rows_of(dv)[2], rows, c, beta)
+                    plan.emit_bwd(lambda bw=bw: call(*bw))
 
         plan.on_backward(build_backward)
         return out

@@ -13,9 +13,23 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# storage-type codes of include/dj_hip.h (DJ_F32 / DJ_F16 / DJ_BF16)
+DT_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def dt_of(t):
+    """Storage-type code of a tensor (None -> DJ_F32)."""
+    return 0 if t is None else DT_CODE[t.dtype]
+
+
+def any16(*tensors):
+    """True when one of the tensors is held in 16 bits: the launch then goes through a `_t` entry point."""
+    return any(t is not None and t.dtype != torch.float32 for t in tensors)
+
+
 def _pixel_ld(t):
-    """Pixel stride (floats) of an NHWC tensor that may be a channel slice of a wider buffer."""
-    assert t.dim() == 4 and t.dtype == torch.float32 and t.is_cuda, "expected float32 CUDA NHWC tensor"
+    """Pixel stride (elements) of an NHWC tensor that may be a channel slice of a wider buffer."""
+    assert t.dim() == 4 and t.dtype in DT_CODE and t.is_cuda, "expected a float32 / float16 / bfloat16 CUDA NHWC tensor"
     b, h, w, c = t.shape
     ld = t.stride(2) if w > 1 else (t.stride(1) if h > 1 else (t.stride(0) if b > 1 else c))
     assert t.stride(3) == 1 or c == 1, "channels must be contiguous"
@@ -86,6 +100,13 @@ def conv2d_fwd(desc, x, w, bias, y, pro_scale=None, pro_shift=None, pro_relu=Fal
     large enough (conv2d_fwd_workspace_floats); `stats_may_split`: a launch with `stats` may then be split too."""
     d = _desc_for(desc, x, y)
     assert w.is_contiguous() and tuple(w.shape) == (d.kernel_h, d.kernel_w, d.in_c, d.out_c)
+    if any16(x, y):
+        flags = int(bool(relu)) | (2 if y_zeroed else 0) | (4 if stats_may_split else 0)
+        check(_lib.load().dj_conv2d_nhwc_fwd_t(d, ptr(x), dt_of(x), ptr(w), ptr(bias), ptr(y), dt_of(y), ptr(pro_scale),
+                                               ptr(pro_shift), int(pro_relu), flags, ptr(stats), None, 0, None, None, None, 0, 0,
+                                               ptr(workspace), workspace.numel() if workspace is not None else 0, _stream()),
+              "dj_conv2d_nhwc_fwd_t")
+        return y
     if workspace is not None:
         flags = int(bool(relu)) | (2 if y_zeroed else 0) | (4 if stats_may_split else 0)
         check(_lib.load().dj_conv2d_nhwc_fwd_ws(d, ptr(x), ptr(w), ptr(bias), ptr(y), ptr(pro_scale), ptr(pro_shift),
@@ -113,6 +134,15 @@ def conv2d_fwd_addrelu(desc, x, w, bias, y, pro_scale, pro_shift, res, res_scale
     d = _desc_for(desc, x, y)
     assert w.is_contiguous() and tuple(w.shape) == (d.kernel_h, d.kernel_w, d.in_c, d.out_c)
     assert tuple(res.shape) == tuple(x.shape) and (sum_out is None or tuple(sum_out.shape) == tuple(x.shape))
+    if any16(x, res, y, sum_out):
+        assert res.dtype == x.dtype, "the residual operand is read like x: same storage type"
+        check(_lib.load().dj_conv2d_nhwc_fwd_t(d, ptr(x), dt_of(x), ptr(w), ptr(bias), ptr(y), dt_of(y), ptr(pro_scale),
+                                               ptr(pro_shift), 1, int(relu), ptr(stats), ptr(res), _pixel_ld(res), ptr(res_scale),
+                                               ptr(res_shift), ptr(sum_out), _pixel_ld(sum_out) if sum_out is not None else 0,
+                                               dt_of(sum_out), ptr(workspace),
+                                               workspace.numel() if workspace is not None else 0, _stream()),
+              "dj_conv2d_nhwc_fwd_t")
+        return y
     if workspace is not None:
         check(_lib.load().dj_conv2d_nhwc_fwd_addrelu_ws(d, ptr(x), ptr(w), ptr(bias), ptr(y), ptr(pro_scale), ptr(pro_shift),
                                                         ptr(res), _pixel_ld(res), ptr(res_scale), ptr(res_shift),
@@ -156,6 +186,11 @@ def conv2d_dgrad(desc, dy, w, dx, bias=None, beta=False, no_split=False):
     """`no_split`: one K range per tile (no fp32 atomics): for the forward use as Conv2DTranspose."""
     d = _desc_for(desc, dx, dy)
     assert w.is_contiguous() and tuple(w.shape) == (d.kernel_h, d.kernel_w, d.in_c, d.out_c)
+    if any16(dy, dx):
+        check(_lib.load().dj_conv2d_nhwc_dgrad_t(d, ptr(dy), dt_of(dy), ptr(w), ptr(bias), ptr(dx), dt_of(dx),
+                                                 int(bool(beta)) | (2 if no_split else 0), None, 0, 0, None, None, None, None,
+                                                 None, _stream()), "dj_conv2d_nhwc_dgrad_t")
+        return dx
     check(_lib.load().dj_conv2d_nhwc_dgrad(d, ptr(dy), ptr(w), ptr(bias), ptr(dx), int(bool(beta)) | (2 if no_split else 0),
                                            _stream()),
           "dj_conv2d_nhwc_dgrad")
@@ -170,6 +205,11 @@ def conv2d_dgrad_bnbwd(desc, dy, w, dx, z, mean, invstd, scale, shift, partial):
     assert tuple(z.shape) == tuple(dx.shape)
     rows = d.batch * d.in_h * d.in_w
     assert partial.is_contiguous() and tuple(partial.shape) == ((rows + 63) // 64, 2, d.in_c)
+    if any16(dy, dx, z):
+        check(_lib.load().dj_conv2d_nhwc_dgrad_t(d, ptr(dy), dt_of(dy), ptr(w), None, ptr(dx), dt_of(dx), 2, ptr(z), _pixel_ld(z),
+                                                 dt_of(z), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), ptr(partial),
+                                                 _stream()), "dj_conv2d_nhwc_dgrad_t")
+        return dx
     check(_lib.load().dj_conv2d_nhwc_dgrad_bnbwd(d, ptr(dy), ptr(w), ptr(dx), ptr(z), _pixel_ld(z), ptr(mean), ptr(invstd),
                                                  ptr(scale), ptr(shift), ptr(partial), _stream()),
           "dj_conv2d_nhwc_dgrad_bnbwd")
@@ -179,6 +219,51 @@ def conv2d_dgrad_bnbwd(desc, dy, w, dx, z, mean, invstd, scale, shift, partial):
 def conv2d_wgrad(desc, x, dy, dw, pro_scale=None, pro_shift=None, pro_relu=False, dw_zeroed=False):
     d = _desc_for(desc, x, dy)
     assert dw.is_contiguous() and tuple(dw.shape) == (d.kernel_h, d.kernel_w, d.in_c, d.out_c)
+    if any16(x, dy):
+        check(_lib.load().dj_conv2d_nhwc_wgrad_t(d, ptr(x), dt_of(x), ptr(dy), dt_of(dy), ptr(dw), ptr(pro_scale), ptr(pro_shift),
+                                                 int(pro_relu), int(dw_zeroed), _stream()), "dj_conv2d_nhwc_wgrad_t")
+        return dw
     check(_lib.load().dj_conv2d_nhwc_wgrad(d, ptr(x), ptr(dy), ptr(dw), ptr(pro_scale), ptr(pro_shift),
                                            int(pro_relu), int(dw_zeroed), _stream()), "dj_conv2d_nhwc_wgrad")
     return dw
+
+
+# ---- elementwise passes that exist in a float and a typed (`_t`) form ---------------------------------------------------
+# -> (entry point, arguments...) for engine.call, chosen by the storage types of the tensors involved
+def affine_act_call(x, ldx, scale, shift, res, ldres, res_scale, res_shift, y, ldy, rows, c, relu):
+    """y = act(x*scale+shift [+ res*res_scale+res_shift])."""
+    if any16(x, res, y):
+        return ("dj_affine_act_t", x, dt_of(x), int(ldx), scale, shift, res, dt_of(res), int(ldres), res_scale, res_shift, y,
+                dt_of(y), int(ldy), int(rows), int(c), int(relu))
+    return ("dj_affine_act", x, int(ldx), scale, shift, res, int(ldres), res_scale, res_shift, y, int(ldy), int(rows), int(c),
+            int(relu))
+
+
+def relu_bwd_call(dy, ld_dy, y, ld_y, dx, ld_dx, rows, c, beta):
+    if any16(dy, y, dx):
+        return ("dj_relu_bwd_t", dy, dt_of(dy), int(ld_dy), y, dt_of(y), int(ld_y), dx, dt_of(dx), int(ld_dx), int(rows), int(c),
+                int(beta))
+    return ("dj_relu_bwd", dy, int(ld_dy), y, int(ld_y), dx, int(ld_dx), int(rows), int(c), int(beta))
+
+
+def copy2d_call(src, ld_src, dst, ld_dst, rows, cols, beta):
+    if any16(src, dst):
+        return ("dj_copy2d_t", src, dt_of(src), int(ld_src), dst, dt_of(dst), int(ld_dst), int(rows), int(cols), int(beta))
+    return ("dj_copy2d", src, int(ld_src), dst, int(ld_dst), int(rows), int(cols), int(beta))
+
+
+def bn_bwd_reduce_call(dy, ld_dy, z, ld_z, mask_y, ld_y, mean, invstd, scale, shift, mode, rows, c, part):
+    if any16(dy, z, mask_y):
+        return ("dj_bn_bwd_reduce_t", dy, dt_of(dy), int(ld_dy), z, dt_of(z), int(ld_z), mask_y, dt_of(mask_y), int(ld_y), mean,
+                invstd, scale, shift, int(mode), int(rows), int(c), part)
+    return ("dj_bn_bwd_reduce", dy, int(ld_dy), z, int(ld_z), mask_y, int(ld_y), mean, invstd, scale, shift, int(mode), int(rows),
+            int(c), part)
+
+
+def bn_bwd_apply_call(dy, ld_dy, z, ld_z, mask_y, ld_y, scale, shift, mode, k0, k1, k2, dz, ld_dz, rows, c, dm, ld_dm, dm_beta):
+    if any16(dy, z, mask_y, dz, dm):
+        return ("dj_bn_bwd_apply_t", dy, dt_of(dy), int(ld_dy), z, dt_of(z), int(ld_z), mask_y, dt_of(mask_y), int(ld_y), scale,
+                shift, int(mode), k0, k1, k2, dz, dt_of(dz), int(ld_dz), int(rows), int(c), dm, dt_of(dm), int(ld_dm),
+                int(dm_beta))
+    return ("dj_bn_bwd_apply", dy, int(ld_dy), z, int(ld_z), mask_y, int(ld_y), scale, shift, int(mode), k0, k1, k2, dz,
+            int(ld_dz), int(rows), int(c), dm, int(ld_dm), int(dm_beta))
