@@ -204,15 +204,19 @@ int dj_conv2d_nhwc_wgrad(const dj_conv2d_desc* d, const float* x, const float* d
  * dj_conv2d_nhwc_fwd_t = dj_conv2d_nhwc_fwd_ws (res == NULL) / dj_conv2d_nhwc_fwd_addrelu_ws (res != NULL: then pro_relu is
  * ignored, the residual operand has x's type): x, res fp32 | fp16; y fp32 | fp16 (rounded AFTER the fp32 bias / ReLU /
  * statistics epilogue); sum_out fp32 | fp16.  Keras call sites: L/models/keras_ssd300_dct_j2d_resnet.py:77-99,128-163. */
-int dj_conv2d_nhwc_fwd_t(const dj_conv2d_desc* d, const void* x, int dt_x, const float* w, const float* bias, void* y,
+int dj_conv2d_nhwc_fwd_t(const dj_conv2d_desc* d, const void* x, int dt_x, const void* w, int dt_w, const float* bias, void* y,
                          int dt_y, const float* pro_scale, const float* pro_shift, int pro_relu, int relu, float* stats,
                          const void* res, int ld_res, const float* res_scale, const float* res_shift, void* sum_out,
                          int ld_sum, int dt_sum, float* workspace, long workspace_floats, void* stream);
 /* dj_conv2d_nhwc_dgrad (z == NULL) / dj_conv2d_nhwc_dgrad_bnbwd (z != NULL: beta must be 0, bias NULL): dy fp32 | bf16,
  * dx any type (bf16 for the gradient of a fp16 activation; accumulates in that type when beta & 1), z fp32 | fp16. */
-int dj_conv2d_nhwc_dgrad_t(const dj_conv2d_desc* d, const void* dy, int dt_dy, const float* w, const float* bias, void* dx,
-                           int dt_dx, int beta, const void* z, int ld_z, int dt_z, const float* mean, const float* invstd,
+int dj_conv2d_nhwc_dgrad_t(const dj_conv2d_desc* d, const void* dy, int dt_dy, const void* w, int dt_w, const float* bias,
+                           void* dx, int dt_dx, int beta, const void* z, int ld_z, int dt_z, const float* mean, const float* invstd,
                            const float* scale, const float* shift, float* partial, void* stream);
+/* `w` of the two entry points above: the fp32 master weights, or their 16-bit shadow in the type the GEMM multiplies in
+ * (fp16 forward, bf16 input gradient), refreshed once per step by dj_shadow_weights: w16[i] = fp16(w[i]) and / or
+ * wbf[i] = bf16(w[i]) for i < n (n a multiple of 4; either output may be NULL). */
+int dj_shadow_weights(const float* w, void* w16, void* wbf, long n, void* stream);
 /* dj_conv2d_nhwc_wgrad: x fp32 | fp16, dy fp32 | bf16; dw is the fp32 gradient of the master weights. */
 int dj_conv2d_nhwc_wgrad_t(const dj_conv2d_desc* d, const void* x, int dt_x, const void* dy, int dt_dy, float* dw,
                            const float* pro_scale, const float* pro_shift, int pro_relu, int dw_zeroed, void* stream);

@@ -79,10 +79,11 @@ SIGNATURES = {
     "dj_conv2d_nhwc_dgrad": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, c_int, c_void_p]),
     "dj_conv2d_nhwc_dgrad_bnbwd": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, c_int, FP, FP, FP, FP, FP, c_void_p]),
     "dj_conv2d_nhwc_wgrad": (c_int, [POINTER(ConvDesc), FP, FP, FP, FP, FP, c_int, c_int, c_void_p]),
-    "dj_conv2d_nhwc_fwd_t": (c_int, [POINTER(ConvDesc), FP, c_int, FP, FP, FP, c_int, FP, FP, c_int, c_int, FP, FP, c_int, FP, FP,
-                                     FP, c_int, c_int, FP, c_long, c_void_p]),
-    "dj_conv2d_nhwc_dgrad_t": (c_int, [POINTER(ConvDesc), FP, c_int, FP, FP, FP, c_int, c_int, FP, c_int, c_int, FP, FP, FP, FP,
-                                       FP, c_void_p]),
+    "dj_conv2d_nhwc_fwd_t": (c_int, [POINTER(ConvDesc), FP, c_int, FP, c_int, FP, FP, c_int, FP, FP, c_int, c_int, FP, FP, c_int, FP,
+                                     FP, FP, c_int, c_int, FP, c_long, c_void_p]),
+    "dj_conv2d_nhwc_dgrad_t": (c_int, [POINTER(ConvDesc), FP, c_int, FP, c_int, FP, FP, c_int, c_int, FP, c_int, c_int, FP, FP, FP,
+                                       FP, FP, c_void_p]),
+    "dj_shadow_weights": (c_int, [FP, FP, FP, c_long, c_void_p]),
     "dj_conv2d_nhwc_wgrad_t": (c_int, [POINTER(ConvDesc), FP, c_int, FP, c_int, FP, FP, FP, c_int, c_int, c_void_p]),
     "dj_affine_act_t": (c_int, [FP, c_int, c_int, FP, FP, FP, c_int, c_int, FP, FP, FP, c_int, c_int, c_long, c_int, c_int,
                                 c_void_p]),

@@ -135,6 +135,8 @@ extern "C" int dj_conv2d_tune_set(int dir, const dj_conv2d_desc* d, int cfg, int
 extern "C" int dj_conv2d_default_config(int dir, const dj_conv2d_desc* d, int* cfg, int* splits);
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+// a thread's 4-element piece: 16 bytes of a fp32 tensor, 8 bytes of a 16-bit one
+static inline bool aligned_dt(const void* p, int dt) { return (((uintptr_t)p) & (dt == 0 ? 15 : 7)) == 0; }
 
 static int check_desc(const dj_conv2d_desc* d) {
   DJ_CHECK_ARG(d != nullptr, "conv desc is null");
@@ -307,8 +309,8 @@ struct FwdResidual {
   int ld_sum = 0;
 };
 
-struct FwdTypes {   // how x (and the residual operand), y and the stored residual sum are held in HBM
-  int x = DJ_F32, y = DJ_F32, sum = DJ_F32;
+struct FwdTypes {   // how x (and the residual operand), the weights, y and the stored residual sum are held in HBM
+  int x = DJ_F32, w = DJ_F32, y = DJ_F32, sum = DJ_F32;
 };
 
 static int conv_fwd_impl(const dj_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y,
@@ -317,9 +319,10 @@ static int conv_fwd_impl(const dj_conv2d_desc* d, const float* x, const float* w
                          const FwdTypes& ty = FwdTypes()) {
   if (int rc = check_desc(d)) return rc;
   DJ_CHECK_ARG(x && w && y, "conv fwd: null tensor");
-  const bool io16 = ty.x != DJ_F32 || ty.y != DJ_F32 || ty.sum != DJ_F32;
-  DJ_CHECK_ARG((ty.x == DJ_F32 || ty.x == DJ_F16) && (ty.y == DJ_F32 || ty.y == DJ_F16) && (ty.sum == DJ_F32 || ty.sum == DJ_F16),
-               "conv fwd: activations are held as fp32 or fp16");
+  const bool io16 = ty.x != DJ_F32 || ty.y != DJ_F32 || ty.sum != DJ_F32 || ty.w != DJ_F32;
+  DJ_CHECK_ARG((ty.x == DJ_F32 || ty.x == DJ_F16) && (ty.y == DJ_F32 || ty.y == DJ_F16) && (ty.sum == DJ_F32 || ty.sum == DJ_F16) &&
+                   (ty.w == DJ_F32 || ty.w == DJ_F16),
+               "conv fwd: activations and the weight shadow are held as fp32 or fp16");
   DJ_CHECK_ARG(!io16 || (dj_compute_mode() == 1 && !rz.bn),
                "conv fwd: 16-bit tensors need arithmetic mode 1 (float16) and no in-kernel BatchNormalization finalize");
   DJ_CHECK_ARG((pro_scale == nullptr) == (pro_shift == nullptr), "conv fwd: pro_scale/pro_shift must come together");
@@ -351,9 +354,9 @@ static int conv_fwd_impl(const dj_conv2d_desc* d, const float* x, const float* w
   const bool stats_may_split = (relu & DJ_CONV_STATS_MAY_SPLIT) != 0 && stats != nullptr && ws != nullptr && !rz.bn;
   relu &= DJ_CONV_RELU;
   p.relu = relu;
-  p.vecA = (d->in_c % 4 == 0) && (d->ld_x % 4 == 0) && aligned16(x) &&
+  p.vecA = (d->in_c % 4 == 0) && (d->ld_x % 4 == 0) && aligned_dt(x, ty.x) &&
            (!pro_scale || (aligned16(pro_scale) && aligned16(pro_shift)));
-  p.vecB = (d->out_c % 4 == 0) && aligned16(w);
+  p.vecB = (d->out_c % 4 == 0) && aligned_dt(w, ty.w);
   p.a_bytes = extent_bytes((long)d->batch * d->in_h * d->in_w, d->ld_x, d->in_c, dt_size(ty.x));
   p.a_dt = ty.x;
   p.c_dt = ty.y;
@@ -368,7 +371,8 @@ static int conv_fwd_impl(const dj_conv2d_desc* d, const float* x, const float* w
     p.a2_bytes = extent_bytes((long)d->batch * d->in_h * d->in_w, rz.ld_res, d->in_c, dt_size(ty.x));
     p.sum_bytes = rz.sum_out ? extent_bytes((long)d->batch * d->in_h * d->in_w, rz.ld_sum, d->in_c, dt_size(ty.sum)) : 0;
   }
-  p.b_bytes = extent_bytes((long)p.K, d->out_c, d->out_c);
+  p.b_bytes = extent_bytes((long)p.K, d->out_c, d->out_c, dt_size(ty.w));
+  p.b_dt = ty.w;
   if (rz.bn) {
     const dj_bn_train& b = *rz.bn;
     DJ_CHECK_ARG(b.acc && b.ticket && b.gamma && b.beta && b.scale && b.shift && b.save_mean && b.save_invstd,
@@ -536,24 +540,25 @@ static int conv_fwd_addrelu_impl(const dj_conv2d_desc* d, const float* x, const 
 
 // Forward convolution over tensors that carry their storage type (include/dj_hip.h): the superset of dj_conv2d_nhwc_fwd_ws
 // (res == NULL) and dj_conv2d_nhwc_fwd_addrelu_ws.
-extern "C" int dj_conv2d_nhwc_fwd_t(const dj_conv2d_desc* d, const void* x, int dt_x, const float* w, const float* bias, void* y,
-                                    int dt_y, const float* pro_scale, const float* pro_shift, int pro_relu, int relu,
+extern "C" int dj_conv2d_nhwc_fwd_t(const dj_conv2d_desc* d, const void* x, int dt_x, const void* w, int dt_w, const float* bias,
+                                    void* y, int dt_y, const float* pro_scale, const float* pro_shift, int pro_relu, int relu,
                                     float* stats, const void* res, int ld_res, const float* res_scale,
                                     const float* res_shift, void* sum_out, int ld_sum, int dt_sum, float* workspace,
                                     long workspace_floats, void* stream) {
-  DJ_CHECK_ARG(dt_ok(dt_x) && dt_ok(dt_y) && dt_ok(dt_sum), "conv fwd: unknown storage type");
+  DJ_CHECK_ARG(dt_ok(dt_x) && dt_ok(dt_w) && dt_ok(dt_y) && dt_ok(dt_sum), "conv fwd: unknown storage type");
   DJ_CHECK_ARG(workspace_floats >= 0 && (workspace != nullptr || workspace_floats == 0), "conv fwd: bad workspace");
   FwdTypes ty;
   ty.x = dt_x;
+  ty.w = dt_w;
   ty.y = dt_y;
   ty.sum = sum_out ? dt_sum : DJ_F32;
   if (res)
-    return conv_fwd_addrelu_impl(d, (const float*)x, w, bias, (float*)y, pro_scale, pro_shift, (const float*)res, ld_res,
+    return conv_fwd_addrelu_impl(d, (const float*)x, (const float*)w, bias, (float*)y, pro_scale, pro_shift, (const float*)res, ld_res,
                                  res_scale, res_shift, (float*)sum_out, ld_sum, relu, stats, workspace, workspace_floats,
                                  stream, ty);
   DJ_CHECK_ARG(!sum_out, "conv fwd: sum_out without res");
-  return conv_fwd_impl(d, (const float*)x, w, bias, (float*)y, pro_scale, pro_shift, pro_relu, relu, stats, FwdResidual(),
-                       stream, workspace, workspace_floats, ty);
+  return conv_fwd_impl(d, (const float*)x, (const float*)w, bias, (float*)y, pro_scale, pro_shift, pro_relu, relu, stats,
+                       FwdResidual(), stream, workspace, workspace_floats, ty);
 }
 
 extern "C" int dj_conv2d_nhwc_fwd_addrelu(const dj_conv2d_desc* d, const float* x, const float* w, const float* bias,
@@ -587,12 +592,13 @@ struct DgradBnBwd {   // dj_conv2d_nhwc_dgrad_bnbwd: see include/dj_hip.h
 };
 
 static int conv_dgrad_impl(const dj_conv2d_desc* d, const float* dy, const float* w, const float* bias, float* dx, int beta,
-                           const DgradBnBwd* bnb, void* stream, int dt_dy = DJ_F32, int dt_dx = DJ_F32) {
+                           const DgradBnBwd* bnb, void* stream, int dt_dy = DJ_F32, int dt_dx = DJ_F32, int dt_w = DJ_F32) {
   if (int rc = check_desc(d)) return rc;
   DJ_CHECK_ARG(dy && w && dx, "conv dgrad: null tensor");
-  const bool io16 = dt_dy != DJ_F32 || dt_dx != DJ_F32 || (bnb && bnb->dt_z != DJ_F32);
-  DJ_CHECK_ARG((dt_dy == DJ_F32 || dt_dy == DJ_BF16) && (!bnb || bnb->dt_z == DJ_F32 || bnb->dt_z == DJ_F16),
-               "conv dgrad: gradients are held as fp32 or bf16, the BatchNormalization input as fp32 or fp16");
+  const bool io16 = dt_dy != DJ_F32 || dt_dx != DJ_F32 || dt_w != DJ_F32 || (bnb && bnb->dt_z != DJ_F32);
+  DJ_CHECK_ARG((dt_dy == DJ_F32 || dt_dy == DJ_BF16) && (dt_w == DJ_F32 || dt_w == DJ_BF16) &&
+                   (!bnb || bnb->dt_z == DJ_F32 || bnb->dt_z == DJ_F16),
+               "conv dgrad: gradients and the weight shadow are held as fp32 or bf16, the BatchNormalization input as fp32 or fp16");
   DJ_CHECK_ARG(!io16 || dj_compute_mode() == 1, "conv dgrad: 16-bit tensors need arithmetic mode 1 (float16)");
   const bool one_k_range = (beta & DJ_DGRAD_NO_SPLIT) != 0;   // no split-K: no arrival-order arithmetic
   beta &= 1;
@@ -622,10 +628,11 @@ static int conv_dgrad_impl(const dj_conv2d_desc* d, const float* dy, const float
   p.bTapStride = (long)d->in_c * d->out_c;
   p.ldc = d->ld_x;
   p.beta = beta;
-  p.vecA = (d->out_c % 4 == 0) && (d->ld_y % 4 == 0) && aligned16(dy);
-  p.vecB = (d->out_c % 4 == 0) && aligned16(w);
+  p.vecA = (d->out_c % 4 == 0) && (d->ld_y % 4 == 0) && aligned_dt(dy, dt_dy);
+  p.vecB = (d->out_c % 4 == 0) && aligned_dt(w, dt_w);
   p.a_bytes = extent_bytes((long)d->batch * d->out_h * d->out_w, d->ld_y, d->out_c, dt_size(dt_dy));
-  p.b_bytes = extent_bytes((long)d->kernel_h * d->kernel_w * d->in_c, d->out_c, d->out_c);
+  p.b_bytes = extent_bytes((long)d->kernel_h * d->kernel_w * d->in_c, d->out_c, d->out_c, dt_size(dt_w));
+  p.b_dt = dt_w;
   p.a_dt = dt_dy;
   p.c_dt = dt_dx;
   const int es_dx = dt_size(dt_dx);
@@ -715,18 +722,20 @@ extern "C" int dj_conv2d_nhwc_dgrad_bnbwd(const dj_conv2d_desc* d, const float* 
 
 // Input gradient over tensors that carry their storage type: the superset of dj_conv2d_nhwc_dgrad (z == NULL) and
 // dj_conv2d_nhwc_dgrad_bnbwd.
-extern "C" int dj_conv2d_nhwc_dgrad_t(const dj_conv2d_desc* d, const void* dy, int dt_dy, const float* w, const float* bias,
-                                      void* dx, int dt_dx, int beta, const void* z, int ld_z, int dt_z, const float* mean,
+extern "C" int dj_conv2d_nhwc_dgrad_t(const dj_conv2d_desc* d, const void* dy, int dt_dy, const void* w, int dt_w,
+                                      const float* bias, void* dx, int dt_dx, int beta, const void* z, int ld_z, int dt_z, const float* mean,
                                       const float* invstd, const float* scale, const float* shift, float* partial,
                                       void* stream) {
-  DJ_CHECK_ARG(dt_ok(dt_dy) && dt_ok(dt_dx) && dt_ok(dt_z), "conv dgrad: unknown storage type");
-  if (!z) return conv_dgrad_impl(d, (const float*)dy, w, bias, (float*)dx, beta, nullptr, stream, dt_dy, dt_dx);
+  DJ_CHECK_ARG(dt_ok(dt_dy) && dt_ok(dt_w) && dt_ok(dt_dx) && dt_ok(dt_z), "conv dgrad: unknown storage type");
+  if (!z)
+    return conv_dgrad_impl(d, (const float*)dy, (const float*)w, bias, (float*)dx, beta, nullptr, stream, dt_dy, dt_dx, dt_w);
   DJ_CHECK_ARG(mean && invstd && partial, "conv dgrad + BN backward statistics: null tensor");
   DJ_CHECK_ARG((scale == nullptr) == (shift == nullptr), "conv dgrad + BN backward statistics: scale/shift must come together");
   DJ_CHECK_ARG(d && ld_z >= d->in_c && !bias && !(beta & 1), "conv dgrad + BN backward statistics: ld_z < in_c, or a bias / "
                                                               "an accumulating launch");
   DgradBnBwd b{(const float*)z, dt_z, ld_z, mean, invstd, scale, shift, partial};
-  return conv_dgrad_impl(d, (const float*)dy, w, nullptr, (float*)dx, DJ_DGRAD_NO_SPLIT, &b, stream, dt_dy, dt_dx);
+  return conv_dgrad_impl(d, (const float*)dy, (const float*)w, nullptr, (float*)dx, DJ_DGRAD_NO_SPLIT, &b, stream, dt_dy, dt_dx,
+                         dt_w);
 }
 
 static int conv_wgrad_impl(const dj_conv2d_desc* d, const float* x, const float* dy, float* dw, const float* pro_scale,
@@ -760,9 +769,9 @@ static int conv_wgrad_impl(const dj_conv2d_desc* d, const float* x, const float*
   p.ldb = d->ld_y;
   p.ldc = d->out_c;
   p.cmap = 0;
-  p.vecA = (d->in_c % 4 == 0) && (d->ld_x % 4 == 0) && aligned16(x) &&
+  p.vecA = (d->in_c % 4 == 0) && (d->ld_x % 4 == 0) && aligned_dt(x, dt_x) &&
            (!pro_scale || (aligned16(pro_scale) && aligned16(pro_shift)));
-  p.vecB = (d->out_c % 4 == 0) && (d->ld_y % 4 == 0) && aligned16(dy);
+  p.vecB = (d->out_c % 4 == 0) && (d->ld_y % 4 == 0) && aligned_dt(dy, dt_dy);
   p.a_bytes = extent_bytes((long)d->batch * d->in_h * d->in_w, d->ld_x, d->in_c, dt_size(dt_x));
   p.b_bytes = extent_bytes((long)d->batch * d->out_h * d->out_w, d->ld_y, d->out_c, dt_size(dt_dy));
   p.a_dt = dt_x;

@@ -92,8 +92,8 @@ int dj_launch_lowp_io(int cfg, const DjIgemmParams& p, int splits, hipStream_t s
   if constexpr (AM == 0 && BMD == 0) {   // (fp16 variants are instantiated for the forward GEMM only)
     if (mode == 1) return launch_lowp_cfg<AM, BMD, 1, AT, BT>(cfg, p, splits, s, fast);
   }
-  if constexpr (AM == 0 && BMD == 0 && AT != 0) {
-    dj_set_error("16-bit activations in HBM need arithmetic mode 1 (float16)");
+  if constexpr (AM == 0 && BMD == 0 && (AT != 0 || BT != 0)) {
+    dj_set_error("16-bit activations / weight shadows in HBM need arithmetic mode 1 (float16)");
     return DJ_ERR_ARG;
   } else {
     return launch_lowp_cfg<AM, BMD, 2, AT, BT>(cfg, p, splits, s, fast);

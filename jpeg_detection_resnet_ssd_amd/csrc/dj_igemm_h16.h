@@ -26,8 +26,9 @@
 // are kept as fp16 and their gradients as bf16 inside the backbone: a thread's 4-element piece is then ONE 8-byte buffer
 // load, stays in two registers until it goes to LDS (half the staging registers, half the bytes in flight per element),
 // is widened to fp32 only where a prologue has arithmetic to do, and goes to LDS untouched when it already has the
-// MFMA's type and there is no prologue (block sums in the forward pass, dy in both gradient GEMMs).  Weights are always
-// the fp32 master copy.  The result C, the stored residual sum and the BatchNormalization input z of the statistics
+// MFMA's type and there is no prologue (block sums in the forward pass, dy in both gradient GEMMs).  Weights are the fp32
+// master copy or its per-step 16-bit shadow (fp16 for the forward GEMM, bf16 for the input gradient: dj_shadow_weights) --
+// the shadow halves the bytes every tile pulls through L2 for its B operand and takes the conversion out of the tiles.  The result C, the stored residual sum and the BatchNormalization input z of the statistics
 // epilogue carry their types at run time (DjIgemmParams::c_dt / sum_dt / bnb_zdt): they are touched once per tile.
 //
 // BK: with 16-bit MFMAs a 32-deep K-step is 2-8 matrix instructions per wave (64-256 cycles) between two barriers, and
@@ -116,7 +117,6 @@ __device__ __forceinline__ dj_short4 dj_round4(f32x4 v) {
 template <int BM, int BN, int AM, int BMD, int PRO, int PREC, int BK = 32, int PF = 1, int EPI = 0, int AT = 0, int BT = 0>
 __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p) {
   static_assert(EPI == 0 || (AM == 1 && BMD == 1), "BatchNormalization backward statistics: input-gradient GEMM only");
-  static_assert(BT == 0 || BMD == 0, "the per-tap transposed B operand is the fp32 weight tensor");
   constexpr int EA = AT ? 2 : 4, EB = BT ? 2 : 4;   // bytes per stored element
   using ARaw = typename DjRaw<AT>::type;
   using BRaw = typename DjRaw<BT>::type;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
     for (int j = 0; j < NB; ++j) {
       int n = n0 + br0 + RPP * j;
       b_ok[j] = n < p.N;
-      b_off[j] = (n * p.ldb + 4 * bc) * 4;
+      b_off[j] = (n * p.ldb + 4 * bc) * EB;
     }
   }
 
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
         rb[j] = dj_buf_ldraw<BT>(rB, ok ? (unsigned)(b_off[j] + base) : DJ_OOB);
       }
     } else {
-      const unsigned base = (unsigned)(t_tap * p.bTapStride + t_c0) * 4u;
+      const unsigned base = (unsigned)(t_tap * p.bTapStride + t_c0) * (unsigned)EB;
 #pragma unroll
       for (int j = 0; j < NB; ++j) rb[j] = dj_buf_ldraw<BT>(rB, (live && b_ok[j]) ? (unsigned)b_off[j] + base : DJ_OOB);
     }

@@ -860,6 +860,25 @@ extern "C" int dj_copy2d_t(const void* src, int dt_src, long ld_src, void* dst, 
   return DJ_OK;
 }
 
+// w16[i] = fp16(w[i]), wbf[i] = bf16(w[i]): the per-step 16-bit shadows of the fp32 master weights that the reduced-
+// precision GEMMs read as their B operand (fp16 in the forward pass, bf16 in the input gradient).  One pass over the flat
+// weight buffer at the head of the forward list: 4 bytes read, 4 written per parameter.
+__global__ __launch_bounds__(256) void dj_shadow_weights_kernel(const float* w, void* w16, void* wbf, long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 v = VecIO<4>::ld(w + 4 * i);
+    if (w16) dj_stt<4>(w16, 4 * i, DJ_F16, v);
+    if (wbf) dj_stt<4>(wbf, 4 * i, DJ_BF16, v);
+  }
+}
+
+extern "C" int dj_shadow_weights(const float* w, void* w16, void* wbf, long n, void* stream) {
+  DJ_CHECK_ARG(w && (w16 || wbf) && n > 0 && n % 4 == 0, "shadow_weights: bad arguments (n must be a multiple of 4)");
+  DJ_CHECK_ARG(al16(w) && al16(w16) && al16(wbf), "shadow_weights: buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(dj_shadow_weights_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, w, w16, wbf, n / 4);
+  DJ_CHECK_LAUNCH("dj_shadow_weights");
+  return DJ_OK;
+}
+
 // dst[r][c] (+)= src[r][c]   (Concatenate / its gradient / Reshape+Concatenate(axis=1))
 template <int VEC>
 __global__ __launch_bounds__(256) void dj_copy2d_kernel(const float* src, long lds, float* dst, long ldd, long rows,

@@ -448,6 +448,17 @@ class Conv2D(Layer):
                                  self.dilation_rate)
         relu = self.activation == "relu"
         wgt, bias = self.kernel.param, (self.bias.param if self.bias is not None else None)
+        # float16 mode: the GEMMs read the per-step 16-bit shadows of the weights (fp16 forward, bf16 input gradient) where
+        # their launch takes the branch-free reduced-precision kernel (a 16-bit operand is an error anywhere else)
+        w_fwd = w_bwd = wgt
+        if plan.store16 and os.environ.get("DJ_WSHADOW", "1") != "0" and x.pad is None:
+            unit = self.strides == (1, 1) or (self.kernel_size == (1, 1) and self.strides[0] == self.strides[1])
+            if cin % 32 == 0 and self.filters % 4 == 0:
+                model.weight_shadows(plan)
+                w_fwd = self.kernel.param16
+            if self.filters % 32 == 0 and cin % 4 == 0 and unit:
+                model.weight_shadows(plan)
+                w_bwd = self.kernel.parambf
         pro = (x.scale, x.shift, x.relu) if x.is_affine else (None, None, False)
         stats = fused_bn = None
         consumers = model.consumers_of(self.outbound[0])
@@ -501,7 +512,7 @@ class Conv2D(Layer):
                                                                  xbuf))
             else:
                 plan.emit_conv(4 if stats is not None else 0, desc,
-                               lambda: Kn.conv2d_fwd_addrelu(desc, zb, wgt, bias, y, zs, zt, rb, rs, rt, xbuf, relu, stats,
+                               lambda: Kn.conv2d_fwd_addrelu(desc, zb, w_fwd, bias, y, zs, zt, rb, rs, rt, xbuf, relu, stats,
                                                              workspace=ws.buf))
             x.pending_add = None
             plan.mark_ready(x)     # the sum exists from here on: its other readers may run beside the main chain
@@ -509,8 +520,8 @@ class Conv2D(Layer):
             plan.emit_conv(4, desc, lambda: Kn.conv2d_fwd_bn(desc, xbuf, wgt, bias, y, bn_arg, pro[0], pro[1], pro[2]))
         else:
             plan.emit_conv(4 if (stats is not None and not split_instead) else 0, desc,
-                           lambda: Kn.conv2d_fwd(desc, xbuf, wgt, bias, y, pro[0], pro[1], pro[2], relu, stats,
-                                                 workspace=ws.buf, stats_may_split=split_instead))
+                           lambda: Kn.conv2d_fwd(desc, xbuf, w_fwd if fused_bn is None else wgt, bias, y, pro[0], pro[1], pro[2],
+                                                 relu, stats, workspace=ws.buf, stats_may_split=split_instead))
         out = Value(y, needs_grad=True, name=self.name)
         if stats is not None:
             out.conv_stats = (stats, stats.shape[0], bias)
@@ -556,13 +567,13 @@ class Conv2D(Layer):
                     msc, msh = (x.scale, x.shift) if x.relu else (None, None)
                     zbuf = x.buf
                     def fused_dgrad():
-                        return Kn.conv2d_dgrad_bnbwd(desc, dy, wgt, dx, zbuf, mean, invstd, msc, msh, part)
+                        return Kn.conv2d_dgrad_bnbwd(desc, dy, w_bwd, dx, zbuf, mean, invstd, msc, msh, part)
                     fused_dgrad.no_split = True      # for the tuners: a registered split-K factor is ignored here
                     plan.emit_conv(9, desc, fused_dgrad, backward=True)   # tuned and recorded apart from plain dgrads
                     x.grad.bwd_partial = (part, nr)
                 else:
                     dx, beta = plan.grad_of(x, zeroed=own_memset and os.environ.get("DJ_ZERO_ARENA", "1") != "0")
-                    plan.emit_conv(1, desc, lambda: Kn.conv2d_dgrad(desc, dy, wgt, dx, None, bool(beta)), backward=True)
+                    plan.emit_conv(1, desc, lambda: Kn.conv2d_dgrad(desc, dy, w_bwd, dx, None, bool(beta)), backward=True)
 
         plan.on_backward(build_backward)
         return out

@@ -146,6 +146,28 @@ class Model(object):
         self._store = dict(flat=flat, grads=grads, vel=vel, n_train=n_train, segments=segs, offsets=offs,
                            sumsq=torch.zeros(len(segs), dtype=torch.float32, device=device))
 
+    def weight_shadows(self, plan):
+        """fp16 and bf16 copies of the flat weight buffer (K.set_floatx('float16')): what the reduced-precision GEMMs read as
+        their B operand -- fp16 in the forward pass, bf16 in the input gradient -- instead of converting the fp32 master
+        weights again in every tile.  `spec.param16` / `spec.parambf` are views like `spec.param`; one dj_shadow_weights
+        launch at the head of `plan`'s forward list refreshes them every step, whoever changed the master copy."""
+        self._ensure_params()
+        st = self._store
+        if "flat16" not in st:
+            n = st["flat"].numel()
+            st["flat16"] = torch.empty(n, dtype=torch.float16, device=self._device)
+            st["flatbf"] = torch.empty(n, dtype=torch.bfloat16, device=self._device)
+            for w in self.weight_specs:
+                a = st["offsets"][id(w)]
+                w.param16 = st["flat16"][a:a + w.size].view(*w.shape)
+                w.parambf = st["flatbf"][a:a + w.size].view(*w.shape)
+            if self._device.type == "cuda":
+                call("dj_shadow_weights", st["flat"], st["flat16"], st["flatbf"], n)
+        if not getattr(plan, "_shadows_refreshed", False):
+            flat, f16, fbf, n = st["flat"], st["flat16"], st["flatbf"], st["flat"].numel()
+            plan.fwd.insert(0, lambda: call("dj_shadow_weights", flat, f16, fbf, n))
+            plan._shadows_refreshed = True
+
     @property
     def flat_gradients(self):
         self._ensure_params()

@@ -100,9 +100,9 @@ def conv2d_fwd(desc, x, w, bias, y, pro_scale=None, pro_shift=None, pro_relu=Fal
     large enough (conv2d_fwd_workspace_floats); `stats_may_split`: a launch with `stats` may then be split too."""
     d = _desc_for(desc, x, y)
     assert w.is_contiguous() and tuple(w.shape) == (d.kernel_h, d.kernel_w, d.in_c, d.out_c)
-    if any16(x, y):
+    if any16(x, y, w):
         flags = int(bool(relu)) | (2 if y_zeroed else 0) | (4 if stats_may_split else 0)
-        check(_lib.load().dj_conv2d_nhwc_fwd_t(d, ptr(x), dt_of(x), ptr(w), ptr(bias), ptr(y), dt_of(y), ptr(pro_scale),
+        check(_lib.load().dj_conv2d_nhwc_fwd_t(d, ptr(x), dt_of(x), ptr(w), dt_of(w), ptr(bias), ptr(y), dt_of(y), ptr(pro_scale),
                                                ptr(pro_shift), int(pro_relu), flags, ptr(stats), None, 0, None, None, None, 0, 0,
                                                ptr(workspace), workspace.numel() if workspace is not None else 0, _stream()),
               "dj_conv2d_nhwc_fwd_t")
@@ -134,9 +134,9 @@ def conv2d_fwd_addrelu(desc, x, w, bias, y, pro_scale, pro_shift, res, res_scale
     d = _desc_for(desc, x, y)
     assert w.is_contiguous() and tuple(w.shape) == (d.kernel_h, d.kernel_w, d.in_c, d.out_c)
     assert tuple(res.shape) == tuple(x.shape) and (sum_out is None or tuple(sum_out.shape) == tuple(x.shape))
-    if any16(x, res, y, sum_out):
+    if any16(x, res, y, sum_out, w):
         assert res.dtype == x.dtype, "the residual operand is read like x: same storage type"
-        check(_lib.load().dj_conv2d_nhwc_fwd_t(d, ptr(x), dt_of(x), ptr(w), ptr(bias), ptr(y), dt_of(y), ptr(pro_scale),
+        check(_lib.load().dj_conv2d_nhwc_fwd_t(d, ptr(x), dt_of(x), ptr(w), dt_of(w), ptr(bias), ptr(y), dt_of(y), ptr(pro_scale),
                                                ptr(pro_shift), 1, int(relu), ptr(stats), ptr(res), _pixel_ld(res), ptr(res_scale),
                                                ptr(res_shift), ptr(sum_out), _pixel_ld(sum_out) if sum_out is not None else 0,
                                                dt_of(sum_out), ptr(workspace),
@@ -186,8 +186,8 @@ def conv2d_dgrad(desc, dy, w, dx, bias=None, beta=False, no_split=False):
     """`no_split`: one K range per tile (no fp32 atomics): for the forward use as Conv2DTranspose."""
     d = _desc_for(desc, dx, dy)
     assert w.is_contiguous() and tuple(w.shape) == (d.kernel_h, d.kernel_w, d.in_c, d.out_c)
-    if any16(dy, dx):
-        check(_lib.load().dj_conv2d_nhwc_dgrad_t(d, ptr(dy), dt_of(dy), ptr(w), ptr(bias), ptr(dx), dt_of(dx),
+    if any16(dy, dx, w):
+        check(_lib.load().dj_conv2d_nhwc_dgrad_t(d, ptr(dy), dt_of(dy), ptr(w), dt_of(w), ptr(bias), ptr(dx), dt_of(dx),
                                                  int(bool(beta)) | (2 if no_split else 0), None, 0, 0, None, None, None, None,
                                                  None, _stream()), "dj_conv2d_nhwc_dgrad_t")
         return dx
@@ -205,8 +205,8 @@ def conv2d_dgrad_bnbwd(desc, dy, w, dx, z, mean, invstd, scale, shift, partial):
     assert tuple(z.shape) == tuple(dx.shape)
     rows = d.batch * d.in_h * d.in_w
     assert partial.is_contiguous() and tuple(partial.shape) == ((rows + 63) // 64, 2, d.in_c)
-    if any16(dy, dx, z):
-        check(_lib.load().dj_conv2d_nhwc_dgrad_t(d, ptr(dy), dt_of(dy), ptr(w), None, ptr(dx), dt_of(dx), 2, ptr(z), _pixel_ld(z),
+    if any16(dy, dx, z, w):
+        check(_lib.load().dj_conv2d_nhwc_dgrad_t(d, ptr(dy), dt_of(dy), ptr(w), dt_of(w), None, ptr(dx), dt_of(dx), 2, ptr(z), _pixel_ld(z),
                                                  dt_of(z), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), ptr(partial),
                                                  _stream()), "dj_conv2d_nhwc_dgrad_t")
         return dx
