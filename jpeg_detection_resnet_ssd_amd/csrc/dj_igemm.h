@@ -230,58 +230,103 @@ __device__ __forceinline__ void dj_store_full_tile(float* ubase, unsigned lane_b
     }
 }
 
-// The same for a C tensor held in 16 bits (c_dt 1 fp16 / 2 bf16; never atomic: a 16-bit result is written by one K range).
-// A lane holds one column of four consecutive rows; neighbouring lanes (columns n, n + 1) swap half of their rounded
-// values so that each stores two packed 32-bit words -- the even lane rows 0-1, the odd lane rows 2-3 of the group --
-// instead of four 2-byte pieces.
-__device__ __forceinline__ unsigned dj_pack16(float lo, float hi, int dt) {
-  if (dt == 1) {
-    const _Float16 a = (_Float16)lo, b = (_Float16)hi;
-    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
-  }
+// Full-tile store loop of the kernels that may be handed a C tensor held in 16 bits (dj_igemm_h16.h; dt 0 fp32, 1 fp16,
+// 2 bf16; a 16-bit result is never atomic: it is written by one K range).  ONE loop over the row groups with the type
+// tested inside a group, after the group's accumulators have been read: a second copy of the loop behind a type test made
+// the compiler read the whole tile's accumulators above the test (128x128 forward kernels 164 -> 228 registers, three
+// waves per SIMD -> two), as dj_store_full_tile's comment describes for the flag combinations.
+// 16-bit form: a lane holds one column of four consecutive rows; neighbouring lanes (columns n, n + 1) swap half of
+// their rounded values so that each stores two packed 32-bit words -- the even lane rows 0-1, the odd lane rows 2-3 of
+// the group -- instead of four 2-byte pieces.
+__device__ __forceinline__ unsigned dj_pack_f16(float lo, float hi) {
+  const _Float16 a = (_Float16)lo, b = (_Float16)hi;
+  return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+__device__ __forceinline__ unsigned dj_pack_bf16(float lo, float hi) {
   const __bf16 a = (__bf16)lo, b = (__bf16)hi;
   return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+__device__ __forceinline__ unsigned dj_pack16(float lo, float hi, int dt) {
+  return dt == 1 ? dj_pack_f16(lo, hi) : dj_pack_bf16(lo, hi);
 }
 __device__ __forceinline__ float dj_widen16(unsigned short u, int dt) {
   return dt == 1 ? (float)__builtin_bit_cast(_Float16, u) : __builtin_bit_cast(float, (unsigned)u << 16);
 }
 
 template <int TM, int TN>
-__device__ __forceinline__ void dj_store_full_tile16(char* ubase, unsigned lane_byte, int l31, const f32x16 (&acc)[TM][TN],
-                                                     const float (&bv)[TN], int ldc, bool beta, bool relu, int dt) {
-  const size_t row_bytes = (size_t)ldc * 2;
+__device__ __forceinline__ void dj_store_full_tile_io(char* ubase, unsigned lane_elem, int l31, const f32x16 (&acc)[TM][TN],
+                                                      const float (&bv)[TN], int ldc, bool beta, bool relu, bool atomic,
+                                                      int dt) {
+  // ubase: the wave's first row and column (wave-uniform), lane_elem: this lane's ELEMENT offset from it
+  const unsigned es = dt ? 2u : 4u;
+  const size_t row_bytes = (size_t)ldc * es;
+  const unsigned lane_byte = lane_elem * es;
   const bool odd = (l31 & 1) != 0;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
+      float v[4][TN];
       char* rowb = ubase + (size_t)(i * 32 + 8 * g) * row_bytes;
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        float v[4];
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = acc[i][j][4 * g + q] + bv[j];
-        if (beta) {
+        for (int j = 0; j < TN; ++j) v[q][j] = acc[i][j][4 * g + q] + bv[j];
+      if (beta) {
+        if (dt == 0) {
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            v[q] += dj_widen16(*reinterpret_cast<const unsigned short*>(rowb + q * row_bytes + j * 64 + lane_byte), dt);
-        }
-        if (relu) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) asm("v_max_f32_e32 %0, 0, %1" : "=v"(v[q]) : "v"(v[q]));
+            for (int j = 0; j < TN; ++j) v[q][j] += *reinterpret_cast<const float*>(rowb + q * row_bytes + j * 128 + lane_byte);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              v[q][j] += dj_widen16(*reinterpret_cast<const unsigned short*>(rowb + q * row_bytes + j * 64 + lane_byte), dt);
         }
-        const unsigned p01 = dj_pack16(v[0], v[1], dt), p23 = dj_pack16(v[2], v[3], dt);
-        // even lane: keeps rows 0-1, hands rows 2-3 to its odd neighbour and gets that lane's rows 0-1
-        const unsigned got = (unsigned)__shfl_xor((int)(odd ? p01 : p23), 1);
-        const unsigned mine = odd ? p23 : p01;
-        // word of row r: (column n, column n + 1) = (even lane's value, odd lane's value)
-        const unsigned w0 = odd ? ((got & 0xFFFFu) | (mine << 16)) : ((mine & 0xFFFFu) | (got << 16));
-        const unsigned w1 = odd ? ((got >> 16) | (mine & 0xFFFF0000u)) : ((mine >> 16) | (got & 0xFFFF0000u));
-        char* base = rowb + (odd ? 2 : 0) * row_bytes + j * 64 + (lane_byte & ~3u);
-        *reinterpret_cast<unsigned*>(base) = w0;
-        *reinterpret_cast<unsigned*>(base + row_bytes) = w1;
       }
-      __builtin_amdgcn_sched_barrier(0);
+      if (relu) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) asm("v_max_f32_e32 %0, 0, %1" : "=v"(v[q][j]) : "v"(v[q][j]));
+      }
+      if (dt == 0) {
+        if (atomic) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) atomicAdd(reinterpret_cast<float*>(rowb + q * row_bytes + j * 128 + lane_byte), v[q][j]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) *reinterpret_cast<float*>(rowb + q * row_bytes + j * 128 + lane_byte) = v[q][j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          unsigned p01, p23;
+          if (dt == 1) {
+            p01 = dj_pack_f16(v[0][j], v[1][j]);
+            p23 = dj_pack_f16(v[2][j], v[3][j]);
+          } else {
+            p01 = dj_pack_bf16(v[0][j], v[1][j]);
+            p23 = dj_pack_bf16(v[2][j], v[3][j]);
+          }
+          // even lane: keeps rows 0-1, hands rows 2-3 to its odd neighbour and gets that lane's rows 0-1
+          const unsigned got = (unsigned)__shfl_xor((int)(odd ? p01 : p23), 1);
+          const unsigned mine = odd ? p23 : p01;
+          // word of a row: (column n, column n + 1) = (even lane's value, odd lane's value)
+          const unsigned w0 = odd ? ((got & 0xFFFFu) | (mine << 16)) : ((mine & 0xFFFFu) | (got << 16));
+          const unsigned w1 = odd ? ((got >> 16) | (mine & 0xFFFF0000u)) : ((mine >> 16) | (got & 0xFFFF0000u));
+          char* base = rowb + (odd ? 2 : 0) * row_bytes + j * 64 + (lane_byte & ~3u);
+          *reinterpret_cast<unsigned*>(base) = w0;
+          *reinterpret_cast<unsigned*>(base + row_bytes) = w1;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);   // one group's values live at a time
     }
 }
 
@@ -402,19 +447,22 @@ __device__ __forceinline__ void dj_igemm_epilogue(const DjIgemmParams& p, f32x16
   }
 
   float* const Cb = p.C + (size_t)ky * p.slab_stride;   // ky: this workgroup's K chunk
-  if (IO16 && p.c_dt != 0) {
-    // C held in 16 bits: one K range per tile (the launcher never splits such a launch), no atomics
+  if (IO16) {
+    // the reduced-precision kernels: C in fp32 (possibly atomic / slabs) or in 16 bits (one K range, never atomic)
     const int dt = p.c_dt;
-    char* const C16 = reinterpret_cast<char*>(p.C);
-    if (p.cmap == 0 && m0 + BM <= p.M && n0 + BN <= p.N && (p.ldc & 1) == 0) {
+    const unsigned es = dt ? 2u : 4u;
+    char* const Cc = reinterpret_cast<char*>(p.C) + (size_t)ky * p.slab_stride * 4;
+    if (p.cmap == 0 && m0 + BM <= p.M && n0 + BN <= p.N && (dt == 0 || (p.ldc & 1) == 0)) {
       float bv[TN];
+      const bool add_bias = p.bias && (!p.atomic || ky == 0);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bv[j] = p.bias ? p.bias[n0 + (wn * TN + j) * 32 + l31] : 0.f;
+      for (int j = 0; j < TN; ++j) bv[j] = add_bias ? p.bias[n0 + (wn * TN + j) * 32 + l31] : 0.f;
       const int uwave = __builtin_amdgcn_readfirstlane(wave);
       const int uwm = uwave / WN, uwn = uwave % WN;
-      char* ubase = C16 + ((size_t)(m0 + uwm * TM * 32) * p.ldc + (n0 + uwn * TN * 32)) * 2;
-      const unsigned lane_byte = (unsigned)(4 * lh * p.ldc + l31) * 2u;
-      dj_store_full_tile16<TM, TN>(ubase, lane_byte, l31, acc, bv, p.ldc, p.beta != 0, p.relu != 0, dt);
+      char* ubase = Cc + ((size_t)(m0 + uwm * TM * 32) * p.ldc + (n0 + uwn * TN * 32)) * es;
+      const unsigned lane_elem = (unsigned)(4 * lh * p.ldc + l31);
+      dj_store_full_tile_io<TM, TN>(ubase, lane_elem, l31, acc, bv, p.ldc, p.beta != 0 && !p.atomic, p.relu != 0 && !p.atomic,
+                                    p.atomic != 0, dt);
     } else {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -437,11 +485,24 @@ __device__ __forceinline__ void dj_igemm_epilogue(const DjIgemmParams& p, f32x16
             int n = n0 + (wn * TN + j) * 32 + l31;
             if (n >= p.N) continue;
             float v = acc[i][j][r];
-            unsigned short* dst = reinterpret_cast<unsigned short*>(C16 + (rowoff + n) * 2);
-            if (p.bias) v += p.bias[n];
-            if (p.beta) v += dj_widen16(*dst, dt);
-            if (p.relu) v = fmaxf(v, 0.f);
-            *dst = (unsigned short)(dj_pack16(v, 0.f, dt) & 0xFFFFu);
+            if (dt == 0) {
+              float* dst = reinterpret_cast<float*>(Cc) + rowoff + n;
+              if (p.atomic) {
+                if (p.bias && ky == 0) v += p.bias[n];
+                atomicAdd(dst, v);
+              } else {
+                if (p.bias) v += p.bias[n];
+                if (p.beta) v += *dst;
+                if (p.relu) v = fmaxf(v, 0.f);
+                *dst = v;
+              }
+            } else {
+              unsigned short* dst = reinterpret_cast<unsigned short*>(Cc + (rowoff + n) * 2);
+              if (p.bias) v += p.bias[n];
+              if (p.beta) v += dj_widen16(*dst, dt);
+              if (p.relu) v = fmaxf(v, 0.f);
+              *dst = (unsigned short)(dj_pack16(v, 0.f, dt) & 0xFFFFu);
+            }
           }
         }
       }
