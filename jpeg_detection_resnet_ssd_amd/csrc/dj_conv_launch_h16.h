@@ -59,25 +59,26 @@ static int launch_lowp(const DjIgemmParams& p, int splits, hipStream_t s, int fa
   // 16-bit tiles in LDS + 16-deep MFMA (dj_igemm_h16.h).  (The round-1 path -- fp32 tiles, fragments rounded at read time,
   // 8-deep MFMA: PREC != 0 of dj_igemm_fast_kernel -- is no longer instantiated; it was kept for A/B runs until the end
   // of round 2: 16.63 ms against 15.04 ms per fp16 step when the 16-bit tiles arrived.)
-  if constexpr (BM * BN < 128 * 128) {   // the 128x128 tile has no registers to spare for a second prefetch set
-    static const bool pf1 = getenv("DJ_H16_PF1") != nullptr;
-    if (pf2 && !pf1) return launch_h16_depth<BM, BN, AM, BMD, PREC, 2, AT, BT>(p, splits, s, fast, deep);
-  }
+  // (round 2: "the 128x128 tile has no registers to spare for a second prefetch set" -- with 16-bit operands a staging set is
+  // half the registers, and the tuner decides: 128x128 with two prefetch sets are configurations 4 and 13)
+  static const bool pf1 = getenv("DJ_H16_PF1") != nullptr;
+  if (pf2 && !pf1) return launch_h16_depth<BM, BN, AM, BMD, PREC, 2, AT, BT>(p, splits, s, fast, deep);
   return launch_h16_depth<BM, BN, AM, BMD, PREC, 1, AT, BT>(p, splits, s, fast, deep);
 }
 
 // Reduced-precision variants behind the fourteen configuration indices of the tuner (the schedule variants of the fp32
 // kernel do not exist here; their indices select K-step depth and prefetch depth of the 16-bit-tile kernel instead):
-//   tile 128x128: 0, 4 = 32-deep; 9 = 64-deep (one prefetch set)
-//   tile 128x64:  1 = 32-deep; 5 = 32-deep, two prefetch sets; 10 = 64-deep; 8, 13 = 64-deep, two prefetch sets
+//   tile 128x128: 0 = 32-deep; 4 = 32-deep, two prefetch sets; 9 = 64-deep; 13 = 64-deep, two prefetch sets
+//   tile 128x64:  1 = 32-deep; 5 = 32-deep, two prefetch sets; 10 = 64-deep; 8 = 64-deep, two prefetch sets
 //   tile 64x64:   2 = 32-deep; 3, 6 = 32-deep, two prefetch sets; 11 = 64-deep; 7, 12 = 64-deep, two prefetch sets
 // (the weight gradient, whose reduction runs over pixels, has 32-deep K-steps only)
 template <int AM, int BMD, int PREC, int AT, int BT>
 static int launch_lowp_cfg(int cfg, const DjIgemmParams& p, int splits, hipStream_t s, int fast) {
-  const int bm = kCfgs[cfg].bm, bn = kCfgs[cfg].bn;
+  int bm = kCfgs[cfg].bm, bn = kCfgs[cfg].bn;
+  if (cfg == CFG_128x64_PK2) bn = 128;   // (index 13 was a twin of 8: it now names the 128x128 tile with two prefetch sets)
   const bool deep = cfg >= CFG_64x64_S1P;
   const bool pf2 = cfg == CFG_128x32 || cfg == CFG_128x64_S1 || cfg == CFG_64x64_S1 || cfg == CFG_64x64_S1P ||
-                   cfg == CFG_128x64_S1P || cfg == CFG_64x64_PK2 || cfg == CFG_128x64_PK2;
+                   cfg == CFG_128x64_S1P || cfg == CFG_64x64_PK2 || cfg == CFG_128x64_PK2 || cfg == CFG_128x128_S1;
   if (bm == 128 && bn == 128) return launch_lowp<128, 128, AM, BMD, PREC, AT, BT>(p, splits, s, fast, deep, pf2);
   if (bm == 128 && bn == 64) return launch_lowp<128, 64, AM, BMD, PREC, AT, BT>(p, splits, s, fast, deep, pf2);
   return launch_lowp<64, 64, AM, BMD, PREC, AT, BT>(p, splits, s, fast, deep, pf2);   // 64x64 and 128x32 requests
