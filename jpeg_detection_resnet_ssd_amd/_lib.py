@@ -170,6 +170,25 @@ def ptr(t):
     return t.data_ptr()
 
 
+# The HIP stream the next launch goes to.  engine.Plan sets it while it runs its launch lists (the main stream, and the side
+# stream around the launches it issues there): a plain attribute instead of torch's stream context manager, whose enter /
+# exit cost ~25 us of host time per side-stream launch -- in the stretches of the step that consist of 5-10 us kernels (the
+# extra-feature layers and predictor heads) the host was what the GPU waited for.  None: torch's current stream.
+import threading
+
+_stream_tls = threading.local()      # per thread: two threads may run plans of their own side by side
+
+
+def set_launch_stream(handle):
+    """Set (None: clear) the calling thread's launch stream; -> the previous setting."""
+    prev = getattr(_stream_tls, "handle", None)
+    _stream_tls.handle = handle
+    return prev
+
+
 def current_stream():
+    h = getattr(_stream_tls, "handle", None)
+    if h is not None:
+        return h
     import torch
     return torch.cuda.current_stream().cuda_stream

@@ -632,6 +632,45 @@ __device__ __forceinline__ void dj_stt(void* base, long idx, int dt, f32x4 v) {
   }
 }
 
+// eight consecutive elements: ONE 16-byte access of a 16-bit tensor (two of a fp32 one) -- twice the bytes in flight per
+// thread of the 4-element form, which is what these HBM-bound passes are short of when every tensor is 16 bits wide
+typedef unsigned int dj_u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 dj_h8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void dj_ld8(const void* base, long idx, int dt, f32x4& lo, f32x4& hi) {
+  if (dt == DJ_F32) {
+    lo = VecIO<4>::ld(reinterpret_cast<const float*>(base) + idx);
+    hi = VecIO<4>::ld(reinterpret_cast<const float*>(base) + idx + 4);
+    return;
+  }
+  const dj_u32x4 v = *reinterpret_cast<const dj_u32x4*>(reinterpret_cast<const unsigned short*>(base) + idx);
+  if (dt == DJ_F16) {
+    const dj_h8 h = __builtin_bit_cast(dj_h8, v);
+    lo = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    hi = f32x4{(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
+  } else {
+    lo = f32x4{__builtin_bit_cast(float, v.x << 16), __builtin_bit_cast(float, v.x & 0xFFFF0000u),
+               __builtin_bit_cast(float, v.y << 16), __builtin_bit_cast(float, v.y & 0xFFFF0000u)};
+    hi = f32x4{__builtin_bit_cast(float, v.z << 16), __builtin_bit_cast(float, v.z & 0xFFFF0000u),
+               __builtin_bit_cast(float, v.w << 16), __builtin_bit_cast(float, v.w & 0xFFFF0000u)};
+  }
+}
+__device__ __forceinline__ void dj_st8(void* base, long idx, int dt, f32x4 lo, f32x4 hi) {
+  if (dt == DJ_F32) {
+    VecIO<4>::st(reinterpret_cast<float*>(base) + idx, lo);
+    VecIO<4>::st(reinterpret_cast<float*>(base) + idx + 4, hi);
+  } else {
+    *reinterpret_cast<dj_u32x4*>(reinterpret_cast<unsigned short*>(base) + idx) =
+        dj_u32x4{dj_pack2(lo.x, lo.y, dt), dj_pack2(lo.z, lo.w, dt), dj_pack2(hi.x, hi.y, dt), dj_pack2(hi.z, hi.w, dt)};
+  }
+}
+__device__ __forceinline__ f32x4 dj_mask4(f32x4 g, f32x4 m) {
+  g.x = (m.x > 0.f) ? g.x : 0.f;
+  g.y = (m.y > 0.f) ? g.y : 0.f;
+  g.z = (m.z > 0.f) ? g.z : 0.f;
+  g.w = (m.w > 0.f) ? g.w : 0.f;
+  return g;
+}
+
 static inline bool dt_known(int dt) { return dt == DJ_F32 || dt == DJ_F16 || dt == DJ_BF16; }
 // 4-element pieces legal: 16-byte aligned base (8 would do for 16-bit) and a pixel stride that is a multiple of 4 elements
 static inline bool vec_ok(const void* p, long ld) { return al16(p) && ld % 4 == 0; }
@@ -763,6 +802,45 @@ __global__ __launch_bounds__(256) void dj_bn_bwd_apply_t_kernel(const void* dy, 
   }
 }
 
+// the 8-elements-per-thread form of the kernel above (C % 8 == 0, pixel strides multiples of 8)
+__global__ __launch_bounds__(256) void dj_bn_bwd_apply_t8_kernel(const void* dy, int dt_dy, int ld_dy, const void* z, int dt_z,
+                                                                  int ld_z, const void* y, int dt_y, int ld_y,
+                                                                  const float* scale, const float* shift, int mask_mode,
+                                                                  const float* k0, const float* k1, const float* k2, void* dz,
+                                                                  int dt_dz, int ld_dz, long rows, int C, void* dmasked,
+                                                                  int dt_dm, int ld_dm, int dm_beta) {
+  using IO = VecIO<4>;
+  const int cv = C / 8;
+  long total = rows * cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i / cv;
+    int c = (int)(i - r * cv) * 8;
+    f32x4 g0, g1, z0, z1, m0 = {1.f, 1.f, 1.f, 1.f}, m1 = {1.f, 1.f, 1.f, 1.f};
+    dj_ld8(dy, r * ld_dy + c, dt_dy, g0, g1);
+    dj_ld8(z, r * ld_z + c, dt_z, z0, z1);
+    if (mask_mode == 1) {
+      dj_ld8(y, r * ld_y + c, dt_y, m0, m1);
+    } else if (mask_mode == 2) {
+      m0 = z0 * IO::ld(scale + c) + IO::ld(shift + c);
+      m1 = z1 * IO::ld(scale + c + 4) + IO::ld(shift + c + 4);
+    }
+    g0 = dj_mask4(g0, m0);
+    g1 = dj_mask4(g1, m1);
+    dj_st8(dz, r * ld_dz + c, dt_dz, IO::ld(k0 + c) * g0 + IO::ld(k1 + c) * z0 + IO::ld(k2 + c),
+           IO::ld(k0 + c + 4) * g1 + IO::ld(k1 + c + 4) * z1 + IO::ld(k2 + c + 4));
+    if (dmasked) {
+      const long o = r * ld_dm + c;
+      if (dm_beta) {
+        f32x4 a0, a1;
+        dj_ld8(dmasked, o, dt_dm, a0, a1);
+        g0 += a0;
+        g1 += a1;
+      }
+      dj_st8(dmasked, o, dt_dm, g0, g1);
+    }
+  }
+}
+
 extern "C" int dj_bn_bwd_apply_t(const void* dy, int dt_dy, int ld_dy, const void* z, int dt_z, int ld_z, const void* y,
                                  int dt_y, int ld_y, const float* scale, const float* shift, int mask_mode, const float* k0,
                                  const float* k1, const float* k2, void* dz, int dt_dz, int ld_dz, long rows, int C,
@@ -778,7 +856,13 @@ extern "C" int dj_bn_bwd_apply_t(const void* dy, int dt_dy, int ld_dy, const voi
   hipStream_t s = (hipStream_t)stream;
   bool v4 = (C % 4 == 0) && vec_ok(dy, ld_dy) && vec_ok(z, ld_z) && vec_ok(dz, ld_dz) && (mask_mode != 1 || vec_ok(y, ld_y)) &&
             al16(scale) && al16(shift) && al16(k0) && al16(k1) && al16(k2) && (!dmasked || vec_ok(dmasked, ld_dm));
-  if (v4)
+  const bool v8 = v4 && (C % 8 == 0) && (ld_dy % 8 == 0) && (ld_z % 8 == 0) && (ld_dz % 8 == 0) &&
+                  (mask_mode != 1 || ld_y % 8 == 0) && (!dmasked || ld_dm % 8 == 0);
+  if (v8)
+    hipLaunchKernelGGL(dj_bn_bwd_apply_t8_kernel, dim3(ew_blocks(rows * (C / 8))), dim3(256), 0, s, dy, dt_dy, ld_dy, z, dt_z,
+                       ld_z, y, dt_y, ld_y, scale, shift, mask_mode, k0, k1, k2, dz, dt_dz, ld_dz, rows, C, dmasked, dt_dm,
+                       ld_dm, dm_beta);
+  else if (v4)
     hipLaunchKernelGGL(dj_bn_bwd_apply_t_kernel<4>, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, s, dy, dt_dy, ld_dy, z, dt_z,
                        ld_z, y, dt_y, ld_y, scale, shift, mask_mode, k0, k1, k2, dz, dt_dz, ld_dz, rows, C, dmasked, dt_dm,
                        ld_dm, dm_beta);

@@ -50,8 +50,21 @@ def _conv(a):
 def call(name, *args):
     """Launch one C-ABI entry point on torch's current HIP stream (tensors -> device pointers)."""
     fn = getattr(_lib.load(), name)
-    rc = fn(*[_conv(a) for a in args], torch.cuda.current_stream().cuda_stream)
+    rc = fn(*[_conv(a) for a in args], _lib.current_stream())
     check(rc, name)
+
+
+def launcher(name, *args):
+    """-> a closure that launches C-ABI entry point `name` with `args` on the current launch stream; tensors are converted
+    to device pointers once, here (plan buffers never move), and kept alive by the closure."""
+    fn = getattr(_lib.load(), name)
+    conv = [_conv(a) for a in args]
+    keep = [a for a in args if isinstance(a, torch.Tensor)]
+
+    def run():
+        check(fn(*conv, _lib.current_stream()), name)
+    run._keep = keep
+    return run
 
 
 def copy2d_multi(parts):
@@ -68,7 +81,7 @@ def copy2d_multi(parts):
     keep = [(p[0], p[2]) for p in parts]   # the tensors stay alive as long as the launcher does
 
     def run():
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = _lib.current_stream()
         for arr, n in chunks:
             check(lib.dj_copy2d_multi(arr, n, stream), "dj_copy2d_multi")
     run._keep = keep
@@ -88,7 +101,7 @@ def colsum_multi(parts):
     keep = [(p[0], p[4]) for p in parts]
 
     def run():
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = _lib.current_stream()
         for arr, n in chunks:
             check(lib.dj_colsum_multi(arr, n, stream), "dj_colsum_multi")
     run._keep = keep
@@ -440,8 +453,7 @@ class Plan(object):
             if not self.side_enabled:
                 return fn()
             side.wait_event(after)
-            with torch.cuda.stream(side):
-                fn()
+            self._launch_on_side(fn)
         self.fwd.append(run)
 
     def side_results(self, values):
@@ -476,6 +488,13 @@ class Plan(object):
         final when it is issued, so it may run on the plan's side stream."""
         self.conv_calls.append((direction, desc, fn))
         if side and backward and self.side_stream is not None:
+            # DJ_SIDE_MIN_MFLOP (A/B switch, default 0 = every weight gradient): launches below that many MFLOP stay on
+            # the main stream -- a hand-over to the side stream is an event record + a cross-queue wait, 20-40 us during
+            # which a 10 us kernel could have run where it stands
+            mflop = 2e-6 * desc.batch * desc.out_h * desc.out_w * desc.out_c * desc.kernel_h * desc.kernel_w * desc.in_c
+            if mflop < float(os.environ.get("DJ_SIDE_MIN_MFLOP", "0")):
+                side = False
+        if side and backward and self.side_stream is not None:
             fn = self._on_side(fn)
         if fwd_after is not None and not backward:
             return self.emit_side(fn, fwd_after)
@@ -489,10 +508,19 @@ class Plan(object):
                 return fn()
             ready.record()                      # everything issued so far on the main stream (dy, the memset)
             side.wait_event(ready)
-            with torch.cuda.stream(side):
-                fn()
+            self._launch_on_side(fn)
             self._side_dirty = True
         return run
+
+    def _launch_on_side(self, fn):
+        """Run the C-ABI launches of `fn` on the side stream: they take their stream from `_lib.current_stream()`, set here
+        (per thread) rather than from torch's current stream, whose context manager costs ~25 us of host time per use.  (`fn` issues
+        nothing but C-ABI launches; work that goes through torch -- collectives -- uses `after_both_streams`.)"""
+        prev = _lib.set_launch_stream(self.side_stream.cuda_stream)
+        try:
+            fn()
+        finally:
+            _lib.set_launch_stream(prev)
 
     def after_both_streams(self, fn):
         """Run `fn` with the side stream current, after everything issued so far on BOTH streams: what `fn` enqueues
@@ -640,19 +668,23 @@ class Plan(object):
     def run_forward(self):
         lib = _lib.load()
         prev = lib.dj_set_thread_compute_mode(self.compute_mode)
+        prev_stream = _lib.set_launch_stream(torch.cuda.current_stream().cuda_stream)   # once per pass, not per launch
         try:
             for f in self.fwd:
                 f()
         finally:
+            _lib.set_launch_stream(prev_stream)
             lib.dj_set_thread_compute_mode(prev)
 
     def run_backward(self):
         lib = _lib.load()
         prev = lib.dj_set_thread_compute_mode(self.compute_mode)
+        prev_stream = _lib.set_launch_stream(torch.cuda.current_stream().cuda_stream)
         try:
             for f in self.bwd:
                 f()
         finally:
+            _lib.set_launch_stream(prev_stream)
             lib.dj_set_thread_compute_mode(prev)
         self.join_side()
         for h in self.hooks_after_backward:

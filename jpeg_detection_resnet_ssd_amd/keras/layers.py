@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from .. import engine
-from ..engine import GradRef, Value, call, query, rows_of
+from ..engine import GradRef, Value, call, launcher, query, rows_of
 from .. import kernels as Kn
 from . import backend as K
 from . import initializers
@@ -203,8 +203,7 @@ def _materialised(v, who, plan=None, allow_pad=False):
         rows, c, ld = rows_of(src.buf)
         y = plan.empty(*src.buf.shape)
         zbuf, sc, sh, relu = src.buf, src.scale, src.shift, int(src.relu)
-        args = Kn.affine_act_call(zbuf, ld, sc, sh, None, 0, None, None, y, c, rows, c, relu)
-        plan.emit(lambda: call(*args))
+        plan.emit(launcher(*Kn.affine_act_call(zbuf, ld, sc, sh, None, 0, None, None, y, c, rows, c, relu)))
         src._mat = y
     return src._mat
 
@@ -383,8 +382,8 @@ class Conv2D(Layer):
         y_p = plan.empty(b, desc.out_h, desc.out_w, n_pad)
         xbuf = x.buf
         ws = plan.conv_workspace(desc, side=after is not None)     # split-K through slabs: no atomics, no cleared y
-        plan.emit_conv(0, desc, lambda: Kn.conv2d_fwd(desc, xbuf, wp, bias_p, y_p, None, None, False, False, None,
-                                                      workspace=ws.buf), fwd_after=after)
+        plan.emit_conv(0, desc, Kn.bound("conv2d_fwd", desc, xbuf, wp, bias_p, y_p, None, None, False, False, None, ws=ws),
+                       fwd_after=after)
         y_p2 = y_p.view(rows, n_pad)
         outs, unpack = [], []
         for l, off in zip(sibs, offs):
@@ -417,8 +416,10 @@ class Conv2D(Layer):
                 split = engine.copy2d_multi([(dwp2[:, off:off + l.filters], n_pad, l.kernel.grad.view(krows, l.filters),
                                               l.filters, krows, l.filters, 0) for l, off in train])
 
+                wg = Kn.bound("conv2d_wgrad", desc, xbuf, dy_p, dwp, dw_zeroed=True)
+
                 def wgrad():
-                    Kn.conv2d_wgrad(desc, xbuf, dy_p, dwp, dw_zeroed=True)
+                    wg()
                     split()          # same stream, right behind the GEMM
                 plan.emit_conv(2, desc, wgrad, backward=True, side=True)
                 for l, _ in train:
@@ -426,7 +427,7 @@ class Conv2D(Layer):
             if x.needs_grad:
                 own_memset = (engine.tuned_splits(1, desc) or 1) > 1
                 dx, beta = plan.grad_of(x, zeroed=own_memset and os.environ.get("DJ_ZERO_ARENA", "1") != "0")
-                plan.emit_conv(1, desc, lambda: Kn.conv2d_dgrad(desc, dy_p, wp, dx, None, bool(beta)), backward=True)
+                plan.emit_conv(1, desc, Kn.bound("conv2d_dgrad", desc, dy_p, wp, dx, None, bool(beta)), backward=True)
 
         plan.on_backward(build_backward)
         return plan.fused_outputs[id(self)]
@@ -508,20 +509,19 @@ class Conv2D(Layer):
             assert pend["consumer"] is self, "a residual sum must be materialised by its first consumer"
             zb, zs, zt, rb, rs, rt = pend["z"], pend["z_scale"], pend["z_shift"], pend["res"], pend["res_scale"], pend["res_shift"]
             if fused_bn is not None:
-                plan.emit_conv(4, desc, lambda: Kn.conv2d_fwd_bn(desc, zb, wgt, bias, y, bn_arg, zs, zt, True, rb, rs, rt,
-                                                                 xbuf))
+                plan.emit_conv(4, desc, Kn.bound("conv2d_fwd_bn", desc, zb, wgt, bias, y, bn_arg, zs, zt, True, rb, rs, rt, xbuf))
             else:
                 plan.emit_conv(4 if stats is not None else 0, desc,
-                               lambda: Kn.conv2d_fwd_addrelu(desc, zb, w_fwd, bias, y, zs, zt, rb, rs, rt, xbuf, relu, stats,
-                                                             workspace=ws.buf))
+                               Kn.bound("conv2d_fwd_addrelu", desc, zb, w_fwd, bias, y, zs, zt, rb, rs, rt, xbuf, relu, stats,
+                                        ws=ws))
             x.pending_add = None
             plan.mark_ready(x)     # the sum exists from here on: its other readers may run beside the main chain
         elif fused_bn is not None:
-            plan.emit_conv(4, desc, lambda: Kn.conv2d_fwd_bn(desc, xbuf, wgt, bias, y, bn_arg, pro[0], pro[1], pro[2]))
+            plan.emit_conv(4, desc, Kn.bound("conv2d_fwd_bn", desc, xbuf, wgt, bias, y, bn_arg, pro[0], pro[1], pro[2]))
         else:
             plan.emit_conv(4 if (stats is not None and not split_instead) else 0, desc,
-                           lambda: Kn.conv2d_fwd(desc, xbuf, w_fwd if fused_bn is None else wgt, bias, y, pro[0], pro[1], pro[2],
-                                                 relu, stats, workspace=ws.buf, stats_may_split=split_instead))
+                           Kn.bound("conv2d_fwd", desc, xbuf, w_fwd if fused_bn is None else wgt, bias, y, pro[0], pro[1], pro[2],
+                                    relu, stats, ws=ws, stats_may_split=split_instead))
         out = Value(y, needs_grad=True, name=self.name)
         if stats is not None:
             out.conv_stats = (stats, stats.shape[0], bias)
@@ -534,7 +534,7 @@ class Conv2D(Layer):
             dy = out.grad.buf
             if relu:
                 rows, c, ld = rows_of(dy)
-                plan.emit_bwd(lambda: call("dj_relu_bwd", dy, ld, y, c, dy, ld, rows, c, 0))
+                plan.emit_bwd(launcher("dj_relu_bwd", dy, ld, y, c, dy, ld, rows, c, 0))
             if self.bias is not None and self.bias.trainable:
                 if bn_consumer:
                     # the only consumer is a training-mode BatchNormalization: it subtracts the batch mean, so
@@ -545,9 +545,8 @@ class Conv2D(Layer):
                     _bias_grad(plan, dy, self.bias)
             if self.kernel.trainable:
                 dw = self.kernel.grad
-                plan.emit_conv(2, desc, lambda: Kn.conv2d_wgrad(desc, xbuf, dy, dw, pro[0], pro[1], pro[2],
-                                                                dw_zeroed=plan.grads_cleared), backward=True,
-                               side=True)
+                plan.emit_conv(2, desc, Kn.bound("conv2d_wgrad", desc, xbuf, dy, dw, pro[0], pro[1], pro[2],
+                                                 dw_zeroed=plan.grads_cleared), backward=True, side=True)
                 plan.note_grad(self.kernel)
             if x.needs_grad:
                 # a first-writer dgrad that accumulates with atomics (split-K) or scatters (stride-2 1x1) clears dx with
@@ -566,14 +565,13 @@ class Conv2D(Layer):
                     part = plan.empty(nr, 2, cin)
                     msc, msh = (x.scale, x.shift) if x.relu else (None, None)
                     zbuf = x.buf
-                    def fused_dgrad():
-                        return Kn.conv2d_dgrad_bnbwd(desc, dy, w_bwd, dx, zbuf, mean, invstd, msc, msh, part)
+                    fused_dgrad = Kn.bound("conv2d_dgrad_bnbwd", desc, dy, w_bwd, dx, zbuf, mean, invstd, msc, msh, part)
                     fused_dgrad.no_split = True      # for the tuners: a registered split-K factor is ignored here
                     plan.emit_conv(9, desc, fused_dgrad, backward=True)   # tuned and recorded apart from plain dgrads
                     x.grad.bwd_partial = (part, nr)
                 else:
                     dx, beta = plan.grad_of(x, zeroed=own_memset and os.environ.get("DJ_ZERO_ARENA", "1") != "0")
-                    plan.emit_conv(1, desc, lambda: Kn.conv2d_dgrad(desc, dy, w_bwd, dx, None, bool(beta)), backward=True)
+                    plan.emit_conv(1, desc, Kn.bound("conv2d_dgrad", desc, dy, w_bwd, dx, None, bool(beta)), backward=True)
 
         plan.on_backward(build_backward)
         return out
@@ -620,7 +618,7 @@ class Conv2DTranspose(Layer):
         assert (desc.out_h, desc.out_w) == (h, w)
         y = plan.empty(b, oh, ow, self.filters)
         wgt, bias = self.kernel.param, (self.bias.param if self.bias is not None else None)
-        plan.emit_conv(1, desc, lambda: Kn.conv2d_dgrad(desc, xbuf, wgt, y, bias, False, no_split=True))
+        plan.emit_conv(1, desc, Kn.bound("conv2d_dgrad", desc, xbuf, wgt, y, bias, False, no_split=True))
         out = Value(y, needs_grad=True, name=self.name)
 
         def build_backward():
@@ -632,14 +630,14 @@ class Conv2DTranspose(Layer):
                 _bias_grad(plan, dy, self.bias)
             if self.kernel.trainable:
                 dw = self.kernel.grad
-                plan.emit_conv(2, desc, lambda: Kn.conv2d_wgrad(desc, dy, xbuf, dw, dw_zeroed=plan.grads_cleared),
+                plan.emit_conv(2, desc, Kn.bound("conv2d_wgrad", desc, dy, xbuf, dw, dw_zeroed=plan.grads_cleared),
                                backward=True)
                 plan.note_grad(self.kernel)
             if x.needs_grad:
                 dx, beta = plan.grad_of(x)
                 if beta:
                     raise NotImplementedError("accumulating Conv2DTranspose input gradient")
-                plan.emit_conv(0, desc, lambda: Kn.conv2d_fwd(desc, dy, wgt, None, dx), backward=True)
+                plan.emit_conv(0, desc, Kn.bound("conv2d_fwd", desc, dy, wgt, None, dx), backward=True)
 
         plan.on_backward(build_backward)
         return out
@@ -681,7 +679,7 @@ class Dense(Layer):
         bias = self.bias.param if self.bias is not None else None
         relu = self.activation == "relu"
         ws = plan.conv_workspace(desc)
-        plan.emit(lambda: Kn.conv2d_fwd(desc, x4, wgt, bias, z, relu=relu, workspace=ws.buf))
+        plan.emit(Kn.bound("conv2d_fwd", desc, x4, wgt, bias, z, relu=relu, ws=ws))
         zv = Value(z.view(b, self.units), needs_grad=True, name=self.name)
         out = zv
         if self.activation == "softmax":
@@ -699,12 +697,12 @@ class Dense(Layer):
                 _bias_grad(plan, dy2, self.bias)
             if self.kernel.trainable:
                 dw = self.kernel.grad.view(1, 1, cin, self.units)
-                plan.emit_bwd(lambda: Kn.conv2d_wgrad(desc, x4, dy, dw))
+                plan.emit_bwd(Kn.bound("conv2d_wgrad", desc, x4, dy, dw))
                 plan.note_grad(self.kernel)
             if x.needs_grad:
                 dx, beta = plan.grad_of(x)
                 dx4 = dx.view(b, 1, 1, cin)
-                plan.emit_bwd(lambda: Kn.conv2d_dgrad(desc, dy, wgt, dx4, None, bool(beta)))
+                plan.emit_bwd(Kn.bound("conv2d_dgrad", desc, dy, wgt, dx4, None, bool(beta)))
 
         # registered before the softmax's builder would be wrong: softmax must run first in backward,
         # so the Dense builder is registered first (builders run in reverse registration order)
@@ -785,8 +783,8 @@ class BatchNormalization(Layer):
                 nrows = query("dj_reduce_rows", rows)
                 partial, conv_bias = plan.empty(nrows, 2, c), None
                 plan.emit(lambda: call("dj_colstats_partial", z, rows, c, ld, partial))
-            plan.emit(lambda: call("dj_bn_train_finalize", partial, nrows, rows, conv_bias, gamma, beta, self.epsilon,
-                                   self.momentum, mm, mv, scale, shift, mean, invstd, c))
+            plan.emit(launcher("dj_bn_train_finalize", partial, nrows, rows, conv_bias, gamma, beta, self.epsilon,
+                               self.momentum, mm, mv, scale, shift, mean, invstd, c))
         out.bn_saved = (mean, invstd)   # a consumer convolution may take this layer's backward statistics itself
 
         def build_backward():
@@ -816,8 +814,8 @@ class BatchNormalization(Layer):
             else:
                 nr = query("dj_reduce_rows", rows)
                 part = plan.empty(nr, 2, c)
-                red = Kn.bn_bwd_reduce_call(dy, ld_dy, z, ld, mask_y, ld_y, mean, invstd, scale, shift, mode, rows, c, part)
-                plan.emit_bwd(lambda: call(*red))
+                plan.emit_bwd(launcher(*Kn.bn_bwd_reduce_call(dy, ld_dy, z, ld, mask_y, ld_y, mean, invstd, scale, shift, mode,
+                                                              rows, c, part)))
             plan.emit_bwd(lambda: call("dj_bn_bwd_finalize", part, nr, rows, gamma, mean, invstd, dgamma, dbeta, k0,
                                        k1, k2, c))
             plan.note_grad(self.gamma)
@@ -835,8 +833,7 @@ class BatchNormalization(Layer):
                 plan.emit_bwd(lambda: call(*app))
             elif also is not None:   # nothing to apply here: the shortcut still needs its masked gradient
                 dm, dm_beta = also
-                rb = Kn.relu_bwd_call(dy, ld_dy, mask_y, ld_y, dm, rows_of(dm)[2], rows, c, int(dm_beta))
-                plan.emit_bwd(lambda: call(*rb))
+                plan.emit_bwd(launcher(*Kn.relu_bwd_call(dy, ld_dy, mask_y, ld_y, dm, rows_of(dm)[2], rows, c, int(dm_beta))))
 
         plan.on_backward(build_backward)
         return out
@@ -866,8 +863,7 @@ class Activation(Layer):
         xbuf = _materialised(x, self.name, plan)
         rows, c, ld = rows_of(xbuf)
         y = plan.empty(*xbuf.shape)
-        act = Kn.affine_act_call(xbuf, ld, None, None, None, 0, None, None, y, c, rows, c, 1)
-        plan.emit(lambda: call(*act))
+        plan.emit(launcher(*Kn.affine_act_call(xbuf, ld, None, None, None, 0, None, None, y, c, rows, c, 1)))
         out = Value(y, needs_grad=x.needs_grad, name=self.name)
 
         def build_backward():
@@ -875,8 +871,7 @@ class Activation(Layer):
                 return
             dy = out.grad.buf
             dx, beta = plan.grad_of(x)
-            rb = Kn.relu_bwd_call(dy, rows_of(dy)[2], y, c, dx, rows_of(dx)[2], rows, c, beta)
-            plan.emit_bwd(lambda: call(*rb))
+            plan.emit_bwd(launcher(*Kn.relu_bwd_call(dy, rows_of(dy)[2], y, c, dx, rows_of(dx)[2], rows, c, beta)))
 
         plan.on_backward(build_backward)
         return out
@@ -935,8 +930,8 @@ class Add(Layer):
             out.pending_add = dict(consumer=first, z=abuf, z_scale=a.scale, z_shift=a.shift, res=bbuf, res_scale=b.scale,
                                    res_shift=b.shift)
         else:
-            act = Kn.affine_act_call(abuf, lda, a.scale, a.shift, bbuf, ldb, b.scale, b.shift, y, c, rows, c, int(relu))
-            plan.emit(lambda: call(*act))
+            plan.emit(launcher(*Kn.affine_act_call(abuf, lda, a.scale, a.shift, bbuf, ldb, b.scale, b.shift, y, c, rows, c,
+                                                   int(relu))))
 
         def build_backward():
             if out.grad is None:
@@ -961,7 +956,7 @@ class Add(Layer):
                         bw = Kn.relu_bwd_call(dy, c, y, c, dv, rows_of(dv)[2], rows, c, beta)
                     else:
                         bw = Kn.copy2d_call(dy, c, dv, rows_of(dv)[2], rows, c, beta)
-                    plan.emit_bwd(lambda bw=bw: call(*bw))
+                    plan.emit_bwd(launcher(*bw))
 
         plan.on_backward(build_backward)
         return out

@@ -9,8 +9,63 @@ from . import _lib
 from ._lib import ConvDesc, check, ptr
 
 
+import threading
+
+_tls = threading.local()      # .recorder: set while `bound` captures a wrapper's C-ABI calls instead of launching them
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.current_stream()
+
+
+class _Recorder(object):
+    """Stands in for the library while a wrapper runs in capture mode: every entry point it would launch is noted with
+    its converted arguments (the trailing stream argument dropped) and reports success."""
+
+    def __init__(self):
+        self.calls = []
+
+    def __getattr__(self, name):
+        def note(*args):
+            self.calls.append((name, args[:-1]))
+            return 0
+        return note
+
+
+def _L():
+    rec = getattr(_tls, "recorder", None)
+    return rec if rec is not None else _lib.load()
+
+
+def bound(name, *args, ws=None, **kwargs):
+    """-> a launcher for `kernels.<name>(*args, **kwargs[, workspace=ws.buf])` whose layout checks, descriptor copy and
+    pointer conversions are done ONCE: the wrapper runs in capture mode the first time (and again if the workspace buffer
+    was replaced), afterwards a launch is the recorded C-ABI call(s) with the current stream appended.  Plan buffers never
+    move, so nothing else can go stale.  (Per conv launch the wrapper costs ~20 us of host time, ~4 ms per training step;
+    the float16 step is 11 ms.)  A wrapper that a test or a profiler has replaced in this module is called through."""
+    orig = globals()[name]
+    state = [None, None]
+
+    def run():
+        f = globals()[name]
+        wsb = ws.buf if ws is not None else None
+        if f is not orig:
+            return f(*args, **kwargs, **({"workspace": wsb} if ws is not None else {}))
+        if state[0] is None or state[1] is not wsb:
+            rec = _Recorder()
+            _tls.recorder = rec
+            try:
+                orig(*args, **kwargs, **({"workspace": wsb} if ws is not None else {}))
+            finally:
+                _tls.recorder = None
+            lib = _lib.load()
+            state[0] = [(getattr(lib, n), a, n) for n, a in rec.calls]
+            state[1] = wsb
+        s = _lib.current_stream()
+        for fn, a, n in state[0]:
+            check(fn(*a, s), n)
+    run.wrapper = name
+    return run
 
 
 # storage-type codes of include/dj_hip.h (DJ_F32 / DJ_F16 / DJ_BF16)
@@ -102,18 +157,18 @@ def conv2d_fwd(desc, x, w, bias, y, pro_scale=None, pro_shift=None, pro_relu=Fal
     assert w.is_contiguous() and tuple(w.shape) == (d.kernel_h, d.kernel_w, d.in_c, d.out_c)
     if any16(x, y, w):
         flags = int(bool(relu)) | (2 if y_zeroed else 0) | (4 if stats_may_split else 0)
-        check(_lib.load().dj_conv2d_nhwc_fwd_t(d, ptr(x), dt_of(x), ptr(w), dt_of(w), ptr(bias), ptr(y), dt_of(y), ptr(pro_scale),
+        check(_L().dj_conv2d_nhwc_fwd_t(d, ptr(x), dt_of(x), ptr(w), dt_of(w), ptr(bias), ptr(y), dt_of(y), ptr(pro_scale),
                                                ptr(pro_shift), int(pro_relu), flags, ptr(stats), None, 0, None, None, None, 0, 0,
                                                ptr(workspace), workspace.numel() if workspace is not None else 0, _stream()),
               "dj_conv2d_nhwc_fwd_t")
         return y
     if workspace is not None:
         flags = int(bool(relu)) | (2 if y_zeroed else 0) | (4 if stats_may_split else 0)
-        check(_lib.load().dj_conv2d_nhwc_fwd_ws(d, ptr(x), ptr(w), ptr(bias), ptr(y), ptr(pro_scale), ptr(pro_shift),
+        check(_L().dj_conv2d_nhwc_fwd_ws(d, ptr(x), ptr(w), ptr(bias), ptr(y), ptr(pro_scale), ptr(pro_shift),
                                                 int(pro_relu), flags, ptr(stats), ptr(workspace), workspace.numel(),
                                                 _stream()), "dj_conv2d_nhwc_fwd_ws")
         return y
-    check(_lib.load().dj_conv2d_nhwc_fwd(d, ptr(x), ptr(w), ptr(bias), ptr(y), ptr(pro_scale), ptr(pro_shift),
+    check(_L().dj_conv2d_nhwc_fwd(d, ptr(x), ptr(w), ptr(bias), ptr(y), ptr(pro_scale), ptr(pro_shift),
                                          int(pro_relu), int(bool(relu)) | (2 if y_zeroed else 0), ptr(stats), _stream()),
           "dj_conv2d_nhwc_fwd")
     return y
@@ -136,7 +191,7 @@ def conv2d_fwd_addrelu(desc, x, w, bias, y, pro_scale, pro_shift, res, res_scale
     assert tuple(res.shape) == tuple(x.shape) and (sum_out is None or tuple(sum_out.shape) == tuple(x.shape))
     if any16(x, res, y, sum_out, w):
         assert res.dtype == x.dtype, "the residual operand is read like x: same storage type"
-        check(_lib.load().dj_conv2d_nhwc_fwd_t(d, ptr(x), dt_of(x), ptr(w), dt_of(w), ptr(bias), ptr(y), dt_of(y), ptr(pro_scale),
+        check(_L().dj_conv2d_nhwc_fwd_t(d, ptr(x), dt_of(x), ptr(w), dt_of(w), ptr(bias), ptr(y), dt_of(y), ptr(pro_scale),
                                                ptr(pro_shift), 1, int(relu), ptr(stats), ptr(res), _pixel_ld(res), ptr(res_scale),
                                                ptr(res_shift), ptr(sum_out), _pixel_ld(sum_out) if sum_out is not None else 0,
                                                dt_of(sum_out), ptr(workspace),
@@ -144,13 +199,13 @@ def conv2d_fwd_addrelu(desc, x, w, bias, y, pro_scale, pro_shift, res, res_scale
               "dj_conv2d_nhwc_fwd_t")
         return y
     if workspace is not None:
-        check(_lib.load().dj_conv2d_nhwc_fwd_addrelu_ws(d, ptr(x), ptr(w), ptr(bias), ptr(y), ptr(pro_scale), ptr(pro_shift),
+        check(_L().dj_conv2d_nhwc_fwd_addrelu_ws(d, ptr(x), ptr(w), ptr(bias), ptr(y), ptr(pro_scale), ptr(pro_shift),
                                                         ptr(res), _pixel_ld(res), ptr(res_scale), ptr(res_shift),
                                                         ptr(sum_out), _pixel_ld(sum_out) if sum_out is not None else 0,
                                                         int(relu), ptr(stats), ptr(workspace), workspace.numel(),
                                                         _stream()), "dj_conv2d_nhwc_fwd_addrelu_ws")
         return y
-    check(_lib.load().dj_conv2d_nhwc_fwd_addrelu(d, ptr(x), ptr(w), ptr(bias), ptr(y), ptr(pro_scale), ptr(pro_shift),
+    check(_L().dj_conv2d_nhwc_fwd_addrelu(d, ptr(x), ptr(w), ptr(bias), ptr(y), ptr(pro_scale), ptr(pro_shift),
                                                  ptr(res), _pixel_ld(res), ptr(res_scale), ptr(res_shift), ptr(sum_out),
                                                  _pixel_ld(sum_out) if sum_out is not None else 0, int(relu), ptr(stats),
                                                  _stream()), "dj_conv2d_nhwc_fwd_addrelu")
@@ -174,7 +229,7 @@ def conv2d_fwd_bn(desc, x, w, bias, y, bn, pro_scale=None, pro_shift=None, pro_r
     import ctypes
     d = _desc_for(desc, x, y)
     assert w.is_contiguous() and tuple(w.shape) == (d.kernel_h, d.kernel_w, d.in_c, d.out_c)
-    check(_lib.load().dj_conv2d_nhwc_fwd_bn(d, ptr(x), ptr(w), ptr(bias), ptr(y), ptr(pro_scale), ptr(pro_shift),
+    check(_L().dj_conv2d_nhwc_fwd_bn(d, ptr(x), ptr(w), ptr(bias), ptr(y), ptr(pro_scale), ptr(pro_shift),
                                             int(pro_relu), ptr(res), _pixel_ld(res) if res is not None else 0,
                                             ptr(res_scale), ptr(res_shift), ptr(sum_out),
                                             _pixel_ld(sum_out) if sum_out is not None else 0, ctypes.byref(bn), _stream()),
@@ -187,11 +242,11 @@ def conv2d_dgrad(desc, dy, w, dx, bias=None, beta=False, no_split=False):
     d = _desc_for(desc, dx, dy)
     assert w.is_contiguous() and tuple(w.shape) == (d.kernel_h, d.kernel_w, d.in_c, d.out_c)
     if any16(dy, dx, w):
-        check(_lib.load().dj_conv2d_nhwc_dgrad_t(d, ptr(dy), dt_of(dy), ptr(w), dt_of(w), ptr(bias), ptr(dx), dt_of(dx),
+        check(_L().dj_conv2d_nhwc_dgrad_t(d, ptr(dy), dt_of(dy), ptr(w), dt_of(w), ptr(bias), ptr(dx), dt_of(dx),
                                                  int(bool(beta)) | (2 if no_split else 0), None, 0, 0, None, None, None, None,
                                                  None, _stream()), "dj_conv2d_nhwc_dgrad_t")
         return dx
-    check(_lib.load().dj_conv2d_nhwc_dgrad(d, ptr(dy), ptr(w), ptr(bias), ptr(dx), int(bool(beta)) | (2 if no_split else 0),
+    check(_L().dj_conv2d_nhwc_dgrad(d, ptr(dy), ptr(w), ptr(bias), ptr(dx), int(bool(beta)) | (2 if no_split else 0),
                                            _stream()),
           "dj_conv2d_nhwc_dgrad")
     return dx
@@ -206,11 +261,11 @@ def conv2d_dgrad_bnbwd(desc, dy, w, dx, z, mean, invstd, scale, shift, partial):
     rows = d.batch * d.in_h * d.in_w
     assert partial.is_contiguous() and tuple(partial.shape) == ((rows + 63) // 64, 2, d.in_c)
     if any16(dy, dx, z, w):
-        check(_lib.load().dj_conv2d_nhwc_dgrad_t(d, ptr(dy), dt_of(dy), ptr(w), dt_of(w), None, ptr(dx), dt_of(dx), 2, ptr(z), _pixel_ld(z),
+        check(_L().dj_conv2d_nhwc_dgrad_t(d, ptr(dy), dt_of(dy), ptr(w), dt_of(w), None, ptr(dx), dt_of(dx), 2, ptr(z), _pixel_ld(z),
                                                  dt_of(z), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), ptr(partial),
                                                  _stream()), "dj_conv2d_nhwc_dgrad_t")
         return dx
-    check(_lib.load().dj_conv2d_nhwc_dgrad_bnbwd(d, ptr(dy), ptr(w), ptr(dx), ptr(z), _pixel_ld(z), ptr(mean), ptr(invstd),
+    check(_L().dj_conv2d_nhwc_dgrad_bnbwd(d, ptr(dy), ptr(w), ptr(dx), ptr(z), _pixel_ld(z), ptr(mean), ptr(invstd),
                                                  ptr(scale), ptr(shift), ptr(partial), _stream()),
           "dj_conv2d_nhwc_dgrad_bnbwd")
     return dx
@@ -220,10 +275,10 @@ def conv2d_wgrad(desc, x, dy, dw, pro_scale=None, pro_shift=None, pro_relu=False
     d = _desc_for(desc, x, dy)
     assert dw.is_contiguous() and tuple(dw.shape) == (d.kernel_h, d.kernel_w, d.in_c, d.out_c)
     if any16(x, dy):
-        check(_lib.load().dj_conv2d_nhwc_wgrad_t(d, ptr(x), dt_of(x), ptr(dy), dt_of(dy), ptr(dw), ptr(pro_scale), ptr(pro_shift),
+        check(_L().dj_conv2d_nhwc_wgrad_t(d, ptr(x), dt_of(x), ptr(dy), dt_of(dy), ptr(dw), ptr(pro_scale), ptr(pro_shift),
                                                  int(pro_relu), int(dw_zeroed), _stream()), "dj_conv2d_nhwc_wgrad_t")
         return dw
-    check(_lib.load().dj_conv2d_nhwc_wgrad(d, ptr(x), ptr(dy), ptr(dw), ptr(pro_scale), ptr(pro_shift),
+    check(_L().dj_conv2d_nhwc_wgrad(d, ptr(x), ptr(dy), ptr(dw), ptr(pro_scale), ptr(pro_shift),
                                            int(pro_relu), int(dw_zeroed), _stream()), "dj_conv2d_nhwc_wgrad")
     return dw
 

@@ -233,7 +233,7 @@ def test_typed_launches_are_refused_outside_their_domain(floatx):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("c,ld_extra", [(256, 0), (96, 32), (30, 2)])
+@pytest.mark.parametrize("c,ld_extra", [(256, 0), (96, 32), (100, 0), (30, 2)])
 def test_typed_elementwise_passes_match_the_float_ones(c, ld_extra, cuda):
     """dj_affine_act_t / dj_bn_bwd_reduce_t / dj_bn_bwd_apply_t / dj_relu_bwd_t / dj_copy2d_t against the float entry points
     on the same (rounded) values: identical up to the one rounding of a 16-bit result; vector and scalar code paths,
