@@ -392,14 +392,20 @@ __device__ __forceinline__ void dj_igemm_epilogue(const DjIgemmParams& p, f32x16
           }
         }
       } else {
+        // two values per instruction (v_pk_add_f32 / v_pk_fma_f32): the even and the odd rows of a lane are summed apart
+        // and joined at the end -- 64 accumulators cost 64 vector instructions instead of 128
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = acc[i][j][r];
-          s += v;
-          q += v * v;
-        }
+          for (int r = 0; r < 16; r += 2) {
+            const f32x2 v = {acc[i][j][r], acc[i][j][r + 1]};
+            s2 += v;
+            q2 += v * v;
+          }
+        s = s2.x + s2.y;
+        q = q2.x + q2.y;
       }
       s += __shfl_xor(s, 32);
       q += __shfl_xor(q, 32);

@@ -395,13 +395,10 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
     }
   };
 
+  // No accumulator clears: the first MFMA of every accumulator takes the constant 0 as its C operand (an inline constant
+  // of the instruction), in a peeled first K-step below.  The clears were 128 v_accvgpr_write per wave of a 128x128 tile --
+  // a tenth of ALL vector instructions of a K = 256 tile, in kernels whose vector pipe is busier than their matrix pipe.
   f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // lane constants of the fragment reads
   //  k-contiguous image: element offset of (row l31, k = 8 h) inside a 32-row tile
@@ -418,7 +415,8 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
     dj_tr4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dj_tr4 __attribute__((address_space(3)))*)(dj_lds_short*)(q + 4 * pitch));
     return dj_s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   };
-  auto compute = [&](const short* sA, const short* sB, int s) {
+  auto compute = [&](auto first_tag, const short* sA, const short* sB, int s) {
+    constexpr bool FIRST = decltype(first_tag)::value;   // this MFMA starts its accumulator
     dj_s16x8 fa[TM], fb[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) fa[i] = frag(sA, Cfg::A_KC, kc_a, tr_a, PA, wm * TM + i, s);
@@ -428,42 +426,60 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
+        f32x16 c = acc[i][j];
+        if (FIRST) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) c[r] = 0.f;
+        }
         if (PREC == 1)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(dj_half8, fa[i]),
-                                                             __builtin_bit_cast(dj_half8, fb[j]), acc[i][j], 0, 0, 0);
+                                                             __builtin_bit_cast(dj_half8, fb[j]), c, 0, 0, 0);
         else
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dj_bf16x8, fa[i]),
-                                                              __builtin_bit_cast(dj_bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+                                                              __builtin_bit_cast(dj_bf16x8, fb[j]), c, 0, 0, 0);
       }
   };
 
   // two LDS stages: tile kt+1 is stored while tile kt is multiplied
-  auto kstep = [&](Regs& load_into, const Regs& store_from, int kt, int k_load, bool live) {
+  using First = std::integral_constant<bool, true>;
+  using Later = std::integral_constant<bool, false>;
+  auto kstep = [&](auto first_tag, Regs& load_into, const Regs& store_from, int kt, int k_load, bool live) {
+    constexpr bool FIRST = decltype(first_tag)::value;   // the tile's first K-step: its first MFMAs start the accumulators
     short* cur = smem + (kt & 1) * Cfg::STAGE_H;
     short* nxt = smem + ((kt + 1) & 1) * Cfg::STAGE_H;
     issue_loads(load_into, k_load, live);
     if (PF == 2) __builtin_amdgcn_sched_barrier(0);   // the loads stay up here, a whole step ahead of their LDS stores
+    if (FIRST) compute(First{}, cur, cur + Cfg::A_H, 0);
 #pragma unroll
-    for (int st = 0; st < BK / 32; ++st) compute(cur, cur + Cfg::A_H, st);
+    for (int st = FIRST ? 1 : 0; st < BK / 32; ++st) compute(Later{}, cur, cur + Cfg::A_H, st);
     store_tiles(store_from, nxt, nxt + Cfg::A_H);
 #pragma unroll
-    for (int st = BK / 32; st < BK / 16; ++st) compute(cur, cur + Cfg::A_H, st);
+    for (int st = BK / 32; st < BK / 16; ++st) compute(Later{}, cur, cur + Cfg::A_H, st);
     __syncthreads();
   };
   issue_loads(r0, kbeg, nk > 0);
   if (PF == 2) issue_loads(r1, kbeg + BK, nk > 1);
   store_tiles(r0, smem, smem + Cfg::A_H);
   __syncthreads();
+  // every K chunk of a launch is non-empty (the launchers derive the number of chunks from the chunk length), so there
+  // is a first K-step that starts the accumulators
+  __builtin_assume(nk > 0);
   if (PF == 2) {
     // step kt: tile kt+2 -> the register set tile kt just left; tile kt+1 (other set) -> LDS
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-      kstep(r0, r1, kt, kbeg + (kt + 2) * BK, kt + 2 < nk);
-      kstep(r1, r0, kt + 1, kbeg + (kt + 3) * BK, kt + 3 < nk);
+    kstep(First{}, r0, r1, 0, kbeg + 2 * BK, 2 < nk);
+    int kt = 1;
+    if (nk > 1) {
+      kstep(Later{}, r1, r0, 1, kbeg + 3 * BK, 3 < nk);
+      kt = 2;
     }
-    if (kt < nk) kstep(r0, r1, kt, kbeg + (kt + 2) * BK, false);
+    for (; kt + 1 < nk; kt += 2) {
+      kstep(Later{}, r0, r1, kt, kbeg + (kt + 2) * BK, kt + 2 < nk);
+      kstep(Later{}, r1, r0, kt + 1, kbeg + (kt + 3) * BK, kt + 3 < nk);
+    }
+    if (kt < nk) kstep(Later{}, r0, r1, kt, kbeg + (kt + 2) * BK, false);
   } else {
-    for (int kt = 0; kt < nk; ++kt) kstep(r0, r0, kt, kbeg + (kt + 1) * BK, kt + 1 < nk);
+    kstep(First{}, r0, r0, 0, kbeg + BK, 1 < nk);
+    for (int kt = 1; kt < nk; ++kt) kstep(Later{}, r0, r0, kt, kbeg + (kt + 1) * BK, kt + 1 < nk);
   }
   dj_igemm_epilogue<BM, BN, 2, 2, EPI == 1, true>(p, acc, smem_base, tile_m, m0, n0, ky);
 }
