@@ -6,18 +6,31 @@
 
 // an input-gradient launch that asks for BatchNormalization backward statistics (p.bnb_z) takes the EPI = 1 twin.
 // AT / BT: how the operands A (and A2) / B are stored in HBM (0 fp32, 1 fp16, 2 bf16), see dj_igemm_h16.h.
-template <int BM, int BN, int AM, int BMD, int PRO, int PREC, int BK, int PF, int AT, int BT>
-static int launch_h16_kernel(int smem_bytes, const DjIgemmParams& p, int splits, hipStream_t s) {
+template <int BM, int BN, int AM, int BMD, int PRO, int PREC, int BK, int PF, int AT, int BT, int NP>
+static int launch_h16_np(int smem_bytes, const DjIgemmParams& p, int splits, hipStream_t s) {
   if constexpr (AM == 1 && BMD == 1 && PRO == 0) {
     if (p.bnb_z) {
       static std::atomic<bool> done1{false};
-      return launch_kernel(dj_igemm_h16_kernel<BM, BN, AM, BMD, PRO, PREC, BK, PF, 1, AT, BT>, smem_bytes, BM, BN, p, splits, s,
-                           &done1, 256);
+      return launch_kernel(dj_igemm_h16_kernel<BM, BN, AM, BMD, PRO, PREC, BK, PF, 1, AT, BT, NP>, smem_bytes, BM, BN, p, splits,
+                           s, &done1, 256);
     }
   }
   static std::atomic<bool> done0{false};
-  return launch_kernel(dj_igemm_h16_kernel<BM, BN, AM, BMD, PRO, PREC, BK, PF, 0, AT, BT>, smem_bytes, BM, BN, p, splits, s,
+  return launch_kernel(dj_igemm_h16_kernel<BM, BN, AM, BMD, PRO, PREC, BK, PF, 0, AT, BT, NP>, smem_bytes, BM, BN, p, splits, s,
                        &done0, 256);
+}
+
+template <int BM, int BN, int AM, int BMD, int PRO, int PREC, int BK, int PF, int AT, int BT>
+static int launch_h16_kernel(int smem_bytes, const DjIgemmParams& p, int splits, hipStream_t s) {
+  // 1x1 kernels without padding (for the weight gradient also stride 1, same pixel grid): the variant without per-K-step
+  // bounds arithmetic (NP of dj_igemm_h16.h); DJ_NO_NP=1 switches it off
+  if constexpr (PRO != 3) {
+    static const bool np_off = getenv("DJ_NO_NP") != nullptr;
+    const bool same_grid = (AM != 2) || (p.sH == 1 && p.sW == 1 && p.rowH == p.srcH && p.rowW == p.srcW);
+    if (!np_off && p.KH == 1 && p.KW == 1 && p.pT == 0 && p.pL == 0 && same_grid)
+      return launch_h16_np<BM, BN, AM, BMD, PRO, PREC, BK, PF, AT, BT, 1>(smem_bytes, p, splits, s);
+  }
+  return launch_h16_np<BM, BN, AM, BMD, PRO, PREC, BK, PF, AT, BT, 0>(smem_bytes, p, splits, s);
 }
 
 // BK: K-step depth of the 16-bit-tile kernel (64: forward / input gradient), PF: K-steps of register prefetch -- see

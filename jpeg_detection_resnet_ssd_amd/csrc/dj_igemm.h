@@ -21,6 +21,7 @@
 #include "dj_common.h"
 
 #define DJ_BK 32
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 struct DjIgemmParams {
   const float* A;
@@ -330,13 +331,75 @@ __device__ __forceinline__ void dj_store_full_tile_io(char* ubase, unsigned lane
     }
 }
 
+// 16-bit C, plain store (no accumulate): the tile goes through LDS so that every lane stores 16 contiguous bytes.
+// In the accumulator layout a lane owns single elements of 32 columns x 2 row groups: stored from there, a 128x128 tile is
+// 32 four-byte stores per lane even with the neighbour-lane packing above, and the stores of a short-K tile cost more than
+// its K-loop -- scalar-width stores are issue-bound (MI355X_MICROARCH.md: a dword store costs ~6x a dwordx4 store per byte).
+// Each wave writes its TM*32 x TN*32 sub-tile, rounded, into a row-major LDS image of its own (64 ds_write_b16 with
+// immediate offsets for a 64x64 sub-tile; pitch + 8 elements keeps the two row groups of a wave on different banks), reads
+// it back 8 elements per lane and issues TM*TN*2 global_store_dwordx4.  The K-loop's LDS is free at this point; the
+// first 4 KB are left to the statistics reduction that other waves may still be reading.
+template <int TM, int TN, int DT>
+__device__ __forceinline__ void dj_tile16_to_lds(short* wl, const f32x16 (&acc)[TM][TN], const float (&bv)[TN], bool relu) {
+  constexpr int PITCH = TN * 32 + 8;
+  const float floor_ = relu ? 0.f : -INFINITY;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const float v = fmaxf(acc[i][j][4 * g + q] + bv[j], floor_);
+          unsigned short h;
+          if (DT == 1) {
+            const _Float16 t = (_Float16)v;
+            h = __builtin_bit_cast(unsigned short, t);
+          } else {
+            const __bf16 t = (__bf16)v;
+            h = __builtin_bit_cast(unsigned short, t);
+          }
+          wl[(i * 32 + 8 * g + q) * PITCH + j * 32] = (short)h;
+        }
+      __builtin_amdgcn_sched_barrier(0);   // one group's values live at a time
+    }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void dj_store_tile16_via_lds(short* wave_lds, char* ubase, int lane, int l31, int lh,
+                                                        const f32x16 (&acc)[TM][TN], const float (&bv)[TN], int ldc, bool relu,
+                                                        int dt) {
+  constexpr int PITCH = TN * 32 + 8;                      // elements
+  constexpr int CH = TN * 4, RPP = 64 / CH;               // 16-byte chunks per row, rows per read pass
+  short* const wl = wave_lds + (4 * lh) * PITCH + l31;
+  // (the type test outside the element loop: inside it the compiler computed both roundings and selected)
+  if (dt == 1)
+    dj_tile16_to_lds<TM, TN, 1>(wl, acc, bv, relu);
+  else
+    dj_tile16_to_lds<TM, TN, 2>(wl, acc, bv, relu);
+  // the wave's own image: written and read by the same wave (LDS operations of a wave complete in order)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int rr = lane / CH, cc = lane - rr * CH;
+  const size_t row_bytes = (size_t)ldc * 2;
+#pragma unroll
+  for (int ps = 0; ps < TM * 32 / RPP; ++ps) {
+    const int row = rr + ps * RPP;
+    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(wave_lds + row * PITCH + cc * 8);
+    *reinterpret_cast<u32x4_t*>(ubase + (size_t)row * row_bytes + cc * 16) = v;
+  }
+}
+
 // Shared epilogue: optional per-tile BatchNormalization statistics of the raw accumulator, then
 // bias / accumulate / ReLU / (atomic) store with an optional strided-pixel row map.
 // BNB: the kernel may be asked for BatchNormalization backward statistics (DjIgemmParams::bnb_z) -- only the
 // input-gradient GEMM is; compiled into every kernel the extra code and its six parameters cost the others registers
 // (128x128 forward variants 160 -> 180 VGPRs, i.e. three waves per SIMD -> two; the residual-add variants 26-42 SGPR spills)
 // IO16: the kernel may be handed 16-bit tensors (c_dt / bnb_zdt: the reduced-precision kernels of dj_igemm_h16.h only)
-template <int BM, int BN, int WM, int WN, bool BNB = false, bool IO16 = false>
+// LDSB: bytes of dynamic LDS the kernel owns (0: unknown -- no LDS-staged stores)
+template <int BM, int BN, int WM, int WN, bool BNB = false, bool IO16 = false, int LDSB = 0>
 __device__ __forceinline__ void dj_igemm_epilogue(const DjIgemmParams& p, f32x16 (&acc)[BM / (32 * WM)][BN / (32 * WN)],
                                                   float* smem, int tile_m, int m0, int n0, int ky) {
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
@@ -467,8 +530,15 @@ __device__ __forceinline__ void dj_igemm_epilogue(const DjIgemmParams& p, f32x16
       const int uwm = uwave / WN, uwn = uwave % WN;
       char* ubase = Cc + ((size_t)(m0 + uwm * TM * 32) * p.ldc + (n0 + uwn * TN * 32)) * es;
       const unsigned lane_elem = (unsigned)(4 * lh * p.ldc + l31);
-      dj_store_full_tile_io<TM, TN>(ubase, lane_elem, l31, acc, bv, p.ldc, p.beta != 0 && !p.atomic, p.relu != 0 && !p.atomic,
-                                    p.atomic != 0, dt);
+      constexpr int WAVE_H = TM * 32 * (TN * 32 + 8);          // elements of a wave's LDS image
+      constexpr bool LDS_FITS = LDSB >= 4096 + WM * WN * WAVE_H * 2;
+      if (LDS_FITS && dt != 0 && !p.beta && (p.ldc & 7) == 0 && ((((size_t)p.C) | ((size_t)n0 * 2)) & 15) == 0) {
+        short* wave_lds = reinterpret_cast<short*>(smem) + 2048 + uwave * WAVE_H;
+        dj_store_tile16_via_lds<TM, TN>(wave_lds, ubase, lane, l31, lh, acc, bv, p.ldc, p.relu != 0, dt);
+      } else {
+        dj_store_full_tile_io<TM, TN>(ubase, lane_elem, l31, acc, bv, p.ldc, p.beta != 0 && !p.atomic, p.relu != 0 && !p.atomic,
+                                      p.atomic != 0, dt);
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {

@@ -114,8 +114,15 @@ __device__ __forceinline__ dj_short4 dj_round4(f32x4 v) {
 // more set of staging registers).
 // EPI: 1 = the epilogue also takes BatchNormalization backward statistics (see dj_igemm_fast.h), input gradient only.
 // AT, BT: storage type of A (and A2) / of B in HBM, see the header comment.
-template <int BM, int BN, int AM, int BMD, int PRO, int PREC, int BK = 32, int PF = 1, int EPI = 0, int AT = 0, int BT = 0>
+// NP: 1 = the gathered operand can never leave its tensor (1x1 kernel, no padding; for the weight gradient also stride 1,
+//     input pixel == output pixel): the K-step has no coordinate adds, bounds tests or offset selects -- a row's validity is
+//     a constant of the tile, a row past M carries an offset that stays out of range whatever is added to it.  Round 2 did
+//     this for the fp32 kernels (NP 1 of dj_igemm_fast.h); here the counters say the kernels are bound by instruction ISSUE
+//     (rocprofv3, 1x1 256->1024 @38x38 forward: instructions issuing in 83 % of a SIMD's cycles, matrix pipe busy 18 %, 37 %
+//     of a wave's life waiting for data), and two thirds of the convolutions of a bottleneck block are 1x1.
+template <int BM, int BN, int AM, int BMD, int PRO, int PREC, int BK = 32, int PF = 1, int EPI = 0, int AT = 0, int BT = 0, int NP = 0>
 __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p) {
+  static_assert(NP == 0 || PRO != 3, "NP: not with the residual-add prologue (which keeps row indices of its own)");
   static_assert(EPI == 0 || (AM == 1 && BMD == 1), "BatchNormalization backward statistics: input-gradient GEMM only");
   constexpr int EA = AT ? 2 : 4, EB = BT ? 2 : 4;   // bytes per stored element
   using ARaw = typename DjRaw<AT>::type;
@@ -161,6 +168,7 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
   const int bc = tid % KCH, br0 = tid / KCH;
 
   int a_off[NA], a_rh[NA], a_rw[NA];
+  unsigned row_valid = 0;   // NP: bit j = row j of this thread exists
   // PRO 3 (1x1, stride 1, unpadded: the input pixel IS the GEMM row): only the row index is kept (-1 past M) and the three
   // byte offsets of a row -- x, the residual operand, the stored sum -- are one 24-bit multiply-add each where they are
   // used; with offsets and coordinates held per row and operand the 64-deep variants needed 268-323 registers (one wave
@@ -187,10 +195,11 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
         a_rh[j] = rh;
         a_rw[j] = rw;
         a_off[j] = ((img * p.srcH * p.srcW + rh * p.srcW + rw) * p.ldsrc + 4 * ac) * EA;
+        row_valid |= 1u << j;
       } else {
         a_rh[j] = -(1 << 28);
         a_rw[j] = -(1 << 28);
-        a_off[j] = 0;
+        a_off[j] = NP ? (int)0x80000000 : 0;
       }
     }
   } else {
@@ -208,8 +217,14 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
         a2_sc[i] = dj_buf_ld4(rS, a2_ok[i] ? (unsigned)a2_c[i] * 4u : DJ_OOB);
         a2_sh[i] = dj_buf_ld4(rT, a2_ok[i] ? (unsigned)a2_c[i] * 4u : DJ_OOB);
       }
+      row_valid |= a2_ok[i] ? (1u << i) : 0u;
+      if (NP) a2_c[i] = a2_ok[i] ? a2_c[i] * EA : (int)0x80000000;   // byte offset of the chunk inside its pixel
     }
   }
+  // NP, weight gradient: byte offset of this thread's pixel row (pixel kbeg + ar0 of the first K-step), advanced per K-step;
+  // a pixel past the chunk reads other (finite) rows of x or nothing and meets a zero dy row
+  int np_row = (NP && AM == 2) ? (kbeg + ar0) * p.ldsrc * EA : 0;
+  const int np_step = BK * p.ldsrc * EA;
   int b_off[NB];
   bool b_ok[NB];
   if (BMD == 0) {
@@ -288,6 +303,13 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
           ra2[j] = dj_buf_ldraw<AT>(rA2, ok ? (__umul24(m, (unsigned)p.ldsrc2) + cb) * (unsigned)EA : DJ_OOB);
           a_valid |= ok ? (1u << j) : 0u;
         }
+      } else if (NP) {
+        // the prefetch past the last K-step (never consumed) is sent out of range by the wave-uniform part of the offset:
+        // on these short-K launches one wasted K-step of loads is an eighth of the traffic
+        a_valid = row_valid;
+        const int udelta = live ? delta : (int)0x80000000;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) ra[j] = dj_buf_ldraw<AT>(rA, (unsigned)(a_off[j] + udelta));
       } else {
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
@@ -298,6 +320,12 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
         a_valid |= ok ? (1u << j) : 0u;
       }
       }
+    } else if (NP) {
+      a_valid = row_valid;
+      const int urow = live ? np_row : (int)0x80000000;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) ra[i] = dj_buf_ldraw<AT>(rA, (unsigned)(urow + a2_c[i]));
+      np_row += np_step;
     } else {
       a_valid = 0;
       const int kp = kcur + ar0;
@@ -367,7 +395,9 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
         f32x4 sc = (AM == 2) ? a2_sc[j] : psc, sh = (AM == 2) ? a2_sh[j] : psh;
         v = v * sc + sh;
         if (PRO == 3) v += dj_raw_to_f32<AT>(ra2[j]) * psc2 + psh2;
-        bool ok = (a_valid >> j) & 1u;
+        // (NP weight gradient: nothing to zero -- a chunk past M has zero scale AND shift, a pixel past the chunk meets a
+        // zero dy row)
+        bool ok = (NP && AM == 2) ? true : (bool)((a_valid >> j) & 1u);
         const float lo = ok ? relu_floor : 0.f, hi = ok ? INFINITY : 0.f;   // ReLU + out-of-bounds zero: one v_med3
         v.x = __builtin_amdgcn_fmed3f(v.x, lo, hi);
         v.y = __builtin_amdgcn_fmed3f(v.y, lo, hi);
@@ -481,5 +511,5 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
     kstep(First{}, r0, r0, 0, kbeg + BK, 1 < nk);
     for (int kt = 1; kt < nk; ++kt) kstep(Later{}, r0, r0, kt, kbeg + (kt + 1) * BK, kt + 1 < nk);
   }
-  dj_igemm_epilogue<BM, BN, 2, 2, EPI == 1, true>(p, acc, smem_base, tile_m, m0, n0, ky);
+  dj_igemm_epilogue<BM, BN, 2, 2, EPI == 1, true, Cfg::SMEM_BYTES>(p, acc, smem_base, tile_m, m0, n0, ky);
 }
