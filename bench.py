@@ -136,7 +136,8 @@ def cpu_baseline(archi, batch, budget_s=25.0):
                       "at batch %d; median step %.2f s" % (len(use), archi, batch, med)}
 
 
-DTYPE_NAME = {"float32": "f32", "float16": "f16/bf16-mfma+f32-acc", "bfloat16": "bf16-mfma+f32-acc"}
+DTYPE_NAME = {"float32": "f32", "float16": "f16/bf16-mfma+f32-acc", "bfloat16": "bf16-mfma+f32-acc",
+              "float32x3": "f32 tensors, f32 products as 3 bf16 MFMAs on hi/lo split operands (~4e-6 rel per GEMM), f32 acc"}
 
 
 def run_workload(archi, floatx, batch, steps, warmup, rank=0, world=1):
@@ -198,7 +199,7 @@ def roofline_of(archi, floatx, batch, value, world, model, plan):
             "note": "whole-step algorithmic conv FLOPs (SURVEY 8(d) table) / step time, per GPU"}
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     for rnd in ("r03", "r02"):
-        traffic_file = os.path.join(prof, "%s_igemm_traffic%s.json" % (rnd, "" if floatx == "float32" else "_f16"))
+        traffic_file = os.path.join(prof, "%s_igemm_traffic%s.json" % (rnd, {"float32": "", "float32x3": "_x3"}.get(floatx, "_f16")))
         if os.path.exists(traffic_file) and archi == "deconv" and batch == 32:
             # offline rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_f_hbm_traffic_pmc.md), bytes per launch
             with open(traffic_file) as f:
@@ -219,7 +220,17 @@ def roofline_of(archi, floatx, batch, value, world, model, plan):
                                    "algorithmic_gflop_per_step": k["flop"] / 1e9,
                                    "algorithmic_gbyte_per_step": k["bytes"] / 1e9,
                                    "algorithmic_gbyte_per_s": k["bytes"] / (k["total_ms"] * 1e-3) / 1e9}
-        if floatx != "float32":
+        if floatx == "float32x3":
+            # three bf16 MFMAs per fp32 product: the matrix pipe executes 3x the algorithmic FLOPs, at the bf16 rate
+            roof.update({"achieved": 3 * per_gpu_tflops, "peak": PEAK_F16_MFMA_TFLOPS, "frac": 3 * per_gpu_tflops / PEAK_F16_MFMA_TFLOPS,
+                         "note": "whole-step conv FLOPs x3 (each fp32 product = 3 bf16 MFMA products) / step time, per GPU, "
+                                 "against the dense bf16 MFMA peak; `useful_fp32` is the algorithmic rate next to the fp32 "
+                                 "MFMA peak the exact mode is bounded by",
+                         "useful_fp32": {"achieved": per_gpu_tflops, "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS,
+                                         "ratio": per_gpu_tflops / PEAK_FP32_MFMA_TFLOPS, "kernel_family_tflops": ktf}})
+            roof["dominant_kernel"]["frac"] = 3 * ktf / PEAK_F16_MFMA_TFLOPS
+            roof["dominant_kernel"]["achieved"] = 3 * ktf
+        elif floatx != "float32":
             # reduced-precision MFMA: the GEMMs are ~16x cheaper, reading / writing the operands is what bounds the
             # family (2.4 TF of arithmetic per GB moved at these shapes against a machine balance of 2500 TF / 8 TB/s =
             # 312 FLOP/B): the roofline of this mode is HBM
@@ -245,7 +256,7 @@ def main(json_out=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--archi", default="deconv", choices=["deconv", "ssd_custom", "up_sampling"])
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (the reference trainer's batch_size)")
-    ap.add_argument("--floatx", default="float32", choices=["float32", "float16", "bfloat16"],
+    ap.add_argument("--floatx", default="float32", choices=["float32", "float16", "bfloat16", "float32x3"],
                     help="conv arithmetic: float32 = exact fp32 MFMA (the headline); float16 / bfloat16 = BASELINE config 5's "
                          "reduced-precision MFMA with fp32 master weights and accumulation (reported with its own dtype)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

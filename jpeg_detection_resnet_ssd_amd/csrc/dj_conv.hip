@@ -24,8 +24,9 @@ std::atomic<bool> g_dj_allow_fast{true};
 extern "C" void dj_set_fast_path(int enable) { g_dj_allow_fast.store(enable != 0, std::memory_order_relaxed); }
 
 // Arithmetic mode.  0: fp32 MFMA everywhere (default).  1: forward GEMMs round their operands to fp16, gradient GEMMs
-// (dgrad, wgrad) to bf16 (gradients need the exponent range); 2: bf16 everywhere.  fp32 accumulation and fp32 tensors in
-// all modes.  A process-wide default (atomic) that a thread can override for its own launches: a plan lowered under one
+// (dgrad, wgrad) to bf16 (gradients need the exponent range); 2: bf16 everywhere; 3 ("float32x3"): fp32 tensors, every
+// product as three bf16 MFMAs on hi / lo split operands (~2^-17 relative per product).  fp32 accumulation in all modes.
+// A process-wide default (atomic) that a thread can override for its own launches: a plan lowered under one
 // mode keeps running in it whatever other models or threads of the process select (engine.Plan sets the override before
 // it launches).
 static std::atomic<int> g_default_compute_mode{0};
@@ -33,12 +34,12 @@ static thread_local int tl_compute_mode = -1;
 int dj_compute_mode() { return tl_compute_mode >= 0 ? tl_compute_mode : g_default_compute_mode.load(std::memory_order_relaxed); }
 extern "C" int dj_set_compute_mode(int mode) {
   int prev = g_default_compute_mode.load(std::memory_order_relaxed);
-  if (mode >= 0 && mode <= 2) g_default_compute_mode.store(mode, std::memory_order_relaxed);
+  if (mode >= 0 && mode <= 3) g_default_compute_mode.store(mode, std::memory_order_relaxed);
   return prev;
 }
 extern "C" int dj_set_thread_compute_mode(int mode) {
   int prev = tl_compute_mode;
-  if (mode >= -1 && mode <= 2) tl_compute_mode = mode;
+  if (mode >= -1 && mode <= 3) tl_compute_mode = mode;
   return prev;
 }
 extern "C" int dj_get_compute_mode(void) { return dj_compute_mode(); }

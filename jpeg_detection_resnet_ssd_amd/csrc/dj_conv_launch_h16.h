@@ -37,19 +37,19 @@ static int launch_h16_kernel(int smem_bytes, const DjIgemmParams& p, int splits,
 // dj_igemm_h16.h
 template <int BM, int BN, int AM, int BMD, int PREC, int BK, int PF, int AT, int BT>
 static int launch_h16(const DjIgemmParams& p, int splits, hipStream_t s, int fast) {
-  using H = DjH16Cfg<BM, BN, AM, BMD, BK>;
+  constexpr int SMEM_BYTES = DjH16Cfg<BM, BN, AM, BMD, BK>::SMEM_BYTES * (PREC == 3 ? 2 : 1);   // float32x3: a hi and a lo image per operand
   if (fast == 3) {
     if constexpr (AM == 0 && BMD == 0) {
-      return launch_h16_kernel<BM, BN, AM, BMD, 3, PREC, BK, PF, AT, BT>(H::SMEM_BYTES, p, splits, s);
+      return launch_h16_kernel<BM, BN, AM, BMD, 3, PREC, BK, PF, AT, BT>(SMEM_BYTES, p, splits, s);
     } else {
       dj_set_error("residual-add prologue outside the forward GEMM");
       return DJ_ERR_ARG;
     }
   }
   if (fast == 1)
-    return launch_h16_kernel<BM, BN, AM, BMD, 0, PREC, BK, PF, AT, BT>(H::SMEM_BYTES, p, splits, s);
+    return launch_h16_kernel<BM, BN, AM, BMD, 0, PREC, BK, PF, AT, BT>(SMEM_BYTES, p, splits, s);
   if constexpr (AM != 1) {  // the input-gradient GEMM has no prologue
-    return launch_h16_kernel<BM, BN, AM, BMD, 1, PREC, BK, PF, AT, BT>(H::SMEM_BYTES, p, splits, s);
+    return launch_h16_kernel<BM, BN, AM, BMD, 1, PREC, BK, PF, AT, BT>(SMEM_BYTES, p, splits, s);
   } else {
     dj_set_error("prologue on the input-gradient GEMM");
     return DJ_ERR_ARG;
@@ -103,6 +103,13 @@ static int launch_lowp_cfg(int cfg, const DjIgemmParams& p, int splits, hipStrea
 template <int AM, int BMD, int AT, int BT>
 int dj_launch_lowp_io(int cfg, const DjIgemmParams& p, int splits, hipStream_t s, int fast, int mode) {
   // A-mode 0 with B-mode 0 is the forward GEMM; everything else carries gradients (bf16: they need the exponent range)
+  if constexpr (AT == 0 && BT == 0) {     // float32x3: fp32 tensors, three bf16 MFMAs per product
+    if (mode == 3) return launch_lowp_cfg<AM, BMD, 3, AT, BT>(cfg, p, splits, s, fast);
+  }
+  if (mode == 3) {
+    dj_set_error("arithmetic mode 3 (float32x3) works on fp32 tensors");
+    return DJ_ERR_ARG;
+  }
   if constexpr (AM == 0 && BMD == 0) {   // (fp16 variants are instantiated for the forward GEMM only)
     if (mode == 1) return launch_lowp_cfg<AM, BMD, 1, AT, BT>(cfg, p, splits, s, fast);
   }

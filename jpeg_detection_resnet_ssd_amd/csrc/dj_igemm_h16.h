@@ -21,6 +21,14 @@
 // BatchNormalization(+ReLU) prologue in fp32 before the rounding, XCD-aware tile order, split-K) and the epilogue are
 // those of the fp32 kernel.
 //
+// PREC 3 ("float32x3", arithmetic mode 3; round 3): fp32 tensors, fp32 RESULTS to ~2^-17, on the bf16 matrix pipe.  The fp32
+// MFMA of gfx950 runs at 157 TFLOP/s, the bf16 MFMA at 2500: an fp32 operand is split, when it goes to LDS, into the bf16
+// nearest to it (hi) and the bf16 nearest to what is left (lo) -- |x - hi - lo| <= 2^-18 |x| -- and a product is three MFMAs,
+// hi*hi + hi*lo + lo*hi, accumulated in fp32 (the dropped terms lo*lo and the two residuals are each <= 2^-18 of the
+// product).  Per-product error ~1e-5 against the 1e-3 bar of the parity tests (exact fp32: 1e-7), at 3/16 of the fp32
+// MFMA's matrix-pipe time.  LDS holds two images per operand (the same bytes as fp32 tiles); everything else -- loads,
+// prologues in fp32 before the split, tap state, XCD order, split-K, epilogues -- is the code of the other modes.
+//
 // Operands in HBM (round 3, BASELINE config 5 proper): AT / BT name how the gathered operand A (and the residual operand
 // A2) and the operand B are STORED -- 0 fp32, 1 fp16, 2 bf16 (DJ_F32 / DJ_F16 / DJ_BF16 of include/dj_hip.h).  Activations
 // are kept as fp16 and their gradients as bf16 inside the backbone: a thread's 4-element piece is then ONE 8-byte buffer
@@ -105,6 +113,17 @@ __device__ __forceinline__ dj_short4 dj_round4(f32x4 v) {
   return dj_to_bf16x4(v);
 }
 
+// float32x3: x -> (hi, lo) with hi = bf16(x), lo = bf16(x - hi); hi to `dst`, lo `lo_off` elements behind it
+__device__ __forceinline__ void dj_split_store(short* dst, f32x4 v, int lo_off) {
+  const dj_short4 hi = dj_to_bf16x4(v);
+  const f32x4 back = {__builtin_bit_cast(float, (unsigned)(unsigned short)hi.x << 16),
+                      __builtin_bit_cast(float, (unsigned)(unsigned short)hi.y << 16),
+                      __builtin_bit_cast(float, (unsigned)(unsigned short)hi.z << 16),
+                      __builtin_bit_cast(float, (unsigned)(unsigned short)hi.w << 16)};
+  *reinterpret_cast<dj_short4*>(dst) = hi;
+  *reinterpret_cast<dj_short4*>(dst + lo_off) = dj_to_bf16x4(v - back);
+}
+
 // PRO: 0 plain A, 1 A*scale[c]+shift[c] (+ReLU) on in-bounds elements, 3 the residual-add prologue of the forward 1x1
 // convolutions, relu(A*scale+shift + A2*scale2+shift2), whose column-tile-0 workgroups also store that sum (fp32) to
 // p.sum_out (see dj_igemm_fast.h).  PREC: 1 fp16, 2 bf16.
@@ -124,12 +143,15 @@ template <int BM, int BN, int AM, int BMD, int PRO, int PREC, int BK = 32, int P
 __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p) {
   static_assert(NP == 0 || PRO != 3, "NP: not with the residual-add prologue (which keeps row indices of its own)");
   static_assert(EPI == 0 || (AM == 1 && BMD == 1), "BatchNormalization backward statistics: input-gradient GEMM only");
+  static_assert(PREC != 3 || (AT == 0 && BT == 0), "float32x3: fp32 tensors");
   constexpr int EA = AT ? 2 : 4, EB = BT ? 2 : 4;   // bytes per stored element
   using ARaw = typename DjRaw<AT>::type;
   using BRaw = typename DjRaw<BT>::type;
   // the piece goes from HBM to LDS as it is: stored in the MFMA's type, no prologue
-  constexpr bool A_COPY = (AT == PREC) && PRO == 0, B_COPY = (BT == PREC);
+  constexpr bool A_COPY = (AT == PREC) && PRO == 0 && PREC != 3, B_COPY = (BT == PREC) && PREC != 3;
   using Cfg = DjH16Cfg<BM, BN, AM, BMD, BK>;
+  constexpr int IMGS = (PREC == 3) ? 2 : 1;           // LDS images per operand: PREC 3 keeps a hi and a lo bf16 image
+  constexpr int STAGE = Cfg::STAGE_H * IMGS;          // elements per LDS stage; the lo images sit Cfg::STAGE_H behind the hi ones
   constexpr int TM = Cfg::TM, TN = Cfg::TN, NA = Cfg::NA, NB = Cfg::NB;
   constexpr int PA = Cfg::PA, PB = Cfg::PB, KCH = Cfg::KCH, RPP = Cfg::RPP;
   constexpr int WN = 2;
@@ -413,13 +435,19 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
                                                   rY, ok ? (int)(e * 2u) : (int)DJ_OOB, 0, 0);
         }
       }
-      *reinterpret_cast<dj_short4*>(dst) = dj_round4<PREC>(v);
+      if constexpr (PREC == 3) {
+        dj_split_store(dst, v, Cfg::STAGE_H);
+      } else {
+        *reinterpret_cast<dj_short4*>(dst) = dj_round4<PREC>(v);
+      }
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       short* dst = (BMD == 0) ? sB + (bkr0 + BKSTEP * j) * PB + 4 * bcn : sB + (br0 + RPP * j) * PB + 4 * bc;
       if constexpr (B_COPY)
         *reinterpret_cast<u32x2*>(dst) = rb[j];
+      else if constexpr (PREC == 3)
+        dj_split_store(dst, dj_raw_to_f32<BT>(rb[j]), Cfg::STAGE_H);
       else
         *reinterpret_cast<dj_short4*>(dst) = dj_round4<PREC>(dj_raw_to_f32<BT>(rb[j]));
     }
@@ -447,11 +475,17 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
   };
   auto compute = [&](auto first_tag, const short* sA, const short* sB, int s) {
     constexpr bool FIRST = decltype(first_tag)::value;   // this MFMA starts its accumulator
-    dj_s16x8 fa[TM], fb[TN];
+    dj_s16x8 fa[TM], fb[TN], fa_lo[PREC == 3 ? TM : 1], fb_lo[PREC == 3 ? TN : 1];
 #pragma unroll
     for (int i = 0; i < TM; ++i) fa[i] = frag(sA, Cfg::A_KC, kc_a, tr_a, PA, wm * TM + i, s);
 #pragma unroll
     for (int j = 0; j < TN; ++j) fb[j] = frag(sB, Cfg::B_KC, kc_b, tr_b, PB, wn * TN + j, s);
+    if constexpr (PREC == 3) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa_lo[i] = frag(sA + Cfg::STAGE_H, Cfg::A_KC, kc_a, tr_a, PA, wm * TM + i, s);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb_lo[j] = frag(sB + Cfg::STAGE_H, Cfg::B_KC, kc_b, tr_b, PB, wn * TN + j, s);
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -461,6 +495,12 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
 #pragma unroll
           for (int r = 0; r < 16; ++r) c[r] = 0.f;
         }
+        if constexpr (PREC == 3) {
+          // the two small products first, the large one last
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dj_bf16x8, fa_lo[i]), __builtin_bit_cast(dj_bf16x8, fb[j]), c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dj_bf16x8, fa[i]), __builtin_bit_cast(dj_bf16x8, fb_lo[j]), c, 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dj_bf16x8, fa[i]), __builtin_bit_cast(dj_bf16x8, fb[j]), c, 0, 0, 0);
+        } else
         if (PREC == 1)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(dj_half8, fa[i]),
                                                              __builtin_bit_cast(dj_half8, fb[j]), c, 0, 0, 0);
@@ -475,8 +515,8 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
   using Later = std::integral_constant<bool, false>;
   auto kstep = [&](auto first_tag, Regs& load_into, const Regs& store_from, int kt, int k_load, bool live) {
     constexpr bool FIRST = decltype(first_tag)::value;   // the tile's first K-step: its first MFMAs start the accumulators
-    short* cur = smem + (kt & 1) * Cfg::STAGE_H;
-    short* nxt = smem + ((kt + 1) & 1) * Cfg::STAGE_H;
+    short* cur = smem + (kt & 1) * STAGE;
+    short* nxt = smem + ((kt + 1) & 1) * STAGE;
     issue_loads(load_into, k_load, live);
     if (PF == 2) __builtin_amdgcn_sched_barrier(0);   // the loads stay up here, a whole step ahead of their LDS stores
     if (FIRST) compute(First{}, cur, cur + Cfg::A_H, 0);
@@ -511,5 +551,5 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
     kstep(First{}, r0, r0, 0, kbeg + BK, 1 < nk);
     for (int kt = 1; kt < nk; ++kt) kstep(Later{}, r0, r0, kt, kbeg + (kt + 1) * BK, kt + 1 < nk);
   }
-  dj_igemm_epilogue<BM, BN, 2, 2, EPI == 1, true, Cfg::SMEM_BYTES>(p, acc, smem_base, tile_m, m0, n0, ky);
+  dj_igemm_epilogue<BM, BN, 2, 2, EPI == 1, true, Cfg::SMEM_BYTES * IMGS>(p, acc, smem_base, tile_m, m0, n0, ky);
 }

@@ -167,6 +167,7 @@ class _TunedByMode(dict):
 _TUNED = _TunedByMode()
 _TUNE_DB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gfx950_conv.json")
 _TUNE_DB_LOWP = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gfx950_conv_f16.json")
+_TUNE_DB_X3 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gfx950_conv_x3.json")
 _DB = {}      # compute mode -> {"dir,geometry...": [cfg, splits, ms]}: tile choices measured on an MI355X, shipped in-tree
 
 
@@ -175,12 +176,17 @@ def _tune_db():
     per geometry, plus a trailing 1 where tools/tune_in_step.py replaced the fastest-alone choice by the one that makes
     the whole training step fastest.  The reduced-precision modes (K.set_floatx('float16' / 'bfloat16')) have a table
     of their own: with an 8-deep MFMA the balance between staging and arithmetic, and with it the best tile, differs
-    (+5.8 % on the fp16 deconv SSD300 step, +3.1 % on ssd_custom).  Geometries a table does not hold are timed at plan
+    (+5.8 % on the fp16 deconv SSD300 step, +3.1 % on ssd_custom); 'float32x3' has a third (two LDS images per operand:
+    the large tiles lose a block per CU).  Geometries a table does not hold are timed at plan
     time; DJ_TUNE_DB=path selects another file, DJ_TUNE_DB=0 ignores the tables."""
     mode = int(_lib.load().dj_get_compute_mode())
     if mode not in _DB:
         _DB[mode] = {}
-        default = _TUNE_DB_LOWP if mode != 0 and os.path.exists(_TUNE_DB_LOWP) else _TUNE_DB
+        default = _TUNE_DB
+        for m, path in ((3, _TUNE_DB_X3), (mode, _TUNE_DB_LOWP)):     # float32x3: its own table, else the 16-bit-tile one
+            if mode == m and mode != 0 and os.path.exists(path):
+                default = path
+                break
         path = os.environ.get("DJ_TUNE_DB", default)
         if path != "0" and os.path.exists(path):
             import json

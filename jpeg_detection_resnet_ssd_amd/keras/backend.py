@@ -22,7 +22,7 @@ def image_data_format():
     return "channels_last"
 
 
-_FLOATX = {0: "float32", 1: "float16", 2: "bfloat16"}
+_FLOATX = {0: "float32", 1: "float16", 2: "bfloat16", 3: "float32x3"}
 
 
 def floatx():
@@ -35,6 +35,8 @@ def set_floatx(value):
     """`K.set_floatx('float16')` selects the mixed-precision convolution arithmetic of BASELINE config 5: forward GEMMs
     on fp16 MFMA, gradient GEMMs on bf16 MFMA, fp32 accumulation; weights, activations, gradients and optimizer state
     stay fp32 tensors (unlike Keras, which would also store float16 variables).  'bfloat16': bf16 in every GEMM.
+    'float32x3' (no Keras counterpart): fp32 tensors and fp32-grade results (~1e-5 relative per product), every product
+    as three bf16 MFMAs on operands split into a high and a low bf16 half when they go to LDS.
     'float32' restores the exact-fp32 MFMA path every 1e-3 parity claim refers to."""
     from .. import _lib
     modes = {v: k for k, v in _FLOATX.items()}

@@ -1,0 +1,171 @@
+"""Arithmetic mode 3, K.set_floatx('float32x3'): fp32 tensors, each product of a convolution GEMM as three bf16 MFMAs on
+operands split into a high and a low bf16 half (dj_igemm_h16.h, PREC 3).  The split leaves 2^-18 of an operand behind and
+the lo*lo term is dropped: <= ~1e-5 per product, a few 1e-6 rel-L2 after random-sign accumulation.  The bounds below are
+3e-5 rel-L2 per GEMM (50x tighter than the fp16 mode's, 30x inside the 1e-3 parity bar of the exact-fp32 mode) and the 1e-3
+bar itself for the whole training step."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+X3_TOL = 3e-5
+
+
+@pytest.fixture()
+def floatx():
+    from jpeg_detection_resnet_ssd_amd.keras import backend as K
+    yield K
+    K.set_floatx("float32")
+
+
+def rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
+
+
+@pytest.mark.parametrize("geom", [(8, 19, 19, 256, 256, 3, 1), (4, 38, 38, 128, 512, 1, 1), (8, 10, 10, 512, 512, 3, 1),
+                                  (4, 38, 38, 256, 128, 1, 2)])
+def test_conv_directions_in_float32x3(geom, floatx):
+    from jpeg_detection_resnet_ssd_amd import kernels as Kn
+    from oracle import keras_ops as ko
+    b, h, w, ci, co, k, s = geom
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(b, h, w, ci, generator=g)
+    wt = torch.randn(k, k, ci, co, generator=g) * (2.0 / (k * k * ci)) ** 0.5
+    bias = torch.randn(co, generator=g)
+    xr, wr = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    yr = ko.conv2d(xr, wr, bias.double(), (s, s), "same")
+    dy = torch.randn(*yr.shape, generator=g) * 1e-4
+    yr.backward(dy.double())
+    desc = Kn.make_conv_desc(b, h, w, ci, co, (k, k), (s, s), "same", (1, 1))
+    xd, wd, dyd = x.cuda(), wt.cuda(), dy.cuda()
+    y, dx, dw = torch.empty_like(dyd), torch.empty_like(xd), torch.zeros_like(wd)
+    y32 = torch.empty_like(dyd)
+    Kn.conv2d_fwd(desc, xd, wd, bias.cuda(), y32)
+    floatx.set_floatx("float32x3")
+    assert floatx.floatx() == "float32x3"
+    Kn.conv2d_fwd(desc, xd, wd, bias.cuda(), y)
+    Kn.conv2d_dgrad(desc, dyd, wd, dx)
+    Kn.conv2d_wgrad(desc, xd, dyd, dw)
+    torch.cuda.synchronize()
+    e = (rel_l2(y.cpu(), yr.detach()), rel_l2(dx.cpu(), xr.grad), rel_l2(dw.cpu(), wr.grad))
+    print("float32x3 %s: fwd %.2e dgrad %.2e wgrad %.2e" % (geom, e[0], e[1], e[2]))
+    assert max(e) <= X3_TOL, e
+    assert not torch.equal(y, y32)              # the split-operand kernels did run (the fp32 MFMA rounds differently)
+
+
+def test_float32x3_refuses_16_bit_tensors(floatx):
+    """Mode 3 is an arithmetic of fp32 tensors: 16-bit storage belongs to mode 1 and is refused here."""
+    from jpeg_detection_resnet_ssd_amd import kernels as Kn
+    desc = Kn.make_conv_desc(4, 19, 19, 256, 256, (1, 1), (1, 1), "same", (1, 1))
+    x = torch.randn(4, 19, 19, 256, device="cuda").half()
+    w = torch.randn(1, 1, 256, 256, device="cuda")
+    y = torch.empty(4, 19, 19, 256, device="cuda")
+    floatx.set_floatx("float32x3")
+    with pytest.raises(Exception):
+        Kn.conv2d_fwd(desc, x, w, None, y)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("geom", [(4, 19, 19, 256, 192, 3, 1, "same"), (3, 10, 10, 512, 256, 1, 1, "valid"),
+                                  (5, 10, 10, 128, 320, 3, 2, "same")])
+def test_float32x3_every_tile_and_k_depth(geom, floatx):
+    """Every configuration index of the tuner under mode 3 = every PREC-3 variant of the 16-bit-tile kernel (tiles, K-step
+    depths, prefetch sets, the no-bounds 1x1 variant), in each direction, with the BN prologue / statistics / residual-add
+    forms and with split-K, against the fp64 oracle at X3_TOL."""
+    from jpeg_detection_resnet_ssd_amd import _lib
+    from jpeg_detection_resnet_ssd_amd import kernels as Kn
+    from oracle import keras_ops as ko
+    lib = _lib.load()
+    b, h, w, ci, co, k, s, pad = geom
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(b, h, w, ci, generator=g)
+    wt = torch.randn(k, k, ci, co, generator=g) * (2.0 / (k * k * ci)) ** 0.5
+    sc, sh = torch.rand(ci, generator=g) + 0.5, torch.randn(ci, generator=g) * 0.5
+    res = torch.randn(b, h, w, ci, generator=g)
+    xa = torch.relu(x * sc + sh)
+    xr, wr = xa.double().requires_grad_(True), wt.double().requires_grad_(True)
+    yr = ko.conv2d(xr, wr, None, (s, s), pad)
+    dy = torch.randn(*yr.shape, generator=g) * 1e-3
+    yr.backward(dy.double())
+    w_plain = wt.double().requires_grad_(True)
+    ko.conv2d(x.double(), w_plain, None, (s, s), pad).backward(dy.double())
+    xs = torch.relu(x * sc + sh + res)
+    ys = ko.conv2d(xs.double(), wt.double(), None, (s, s), pad) if (k == 1 and s == 1) else None
+    desc = Kn.make_conv_desc(b, h, w, ci, co, (k, k), (s, s), pad, (1, 1))
+    rows = Kn.conv2d_stats_rows(desc)
+    xd, wd, dyd, scd, shd, resd = [t.cuda() for t in (x, wt, dy, sc, sh, res)]
+    floatx.set_floatx("float32x3")
+    try:
+        for cfg in range(lib.dj_conv2d_tune_configs()):
+            for splits in (1, 2):
+                tag = "cfg %d splits %d" % (cfg, splits)
+                y = torch.empty(yr.shape, device="cuda")
+                stats = torch.zeros(rows, 2, co, device="cuda")
+                _lib.check(lib.dj_conv2d_tune_set(4, desc, cfg, 1), "tune_set")
+                Kn.conv2d_fwd(desc, xd, wd, None, y, scd, shd, True, False, stats)
+                _lib.check(lib.dj_conv2d_tune_set(0, desc, cfg, splits), "tune_set")
+                y0 = torch.zeros(yr.shape, device="cuda")
+                Kn.conv2d_fwd(desc, xd, wd, None, y0, scd, shd, True, False, None, y_zeroed=True)
+                dx = torch.empty(x.shape, device="cuda")
+                _lib.check(lib.dj_conv2d_tune_set(1, desc, cfg, splits), "tune_set")
+                Kn.conv2d_dgrad(desc, dyd, wd, dx)
+                _lib.check(lib.dj_conv2d_tune_set(2, desc, cfg, splits), "tune_set")
+                dw_pro, dw_plain = torch.zeros(wt.shape, device="cuda"), torch.full(wt.shape, 7.0, device="cuda")
+                Kn.conv2d_wgrad(desc, xd, dyd, dw_pro, scd, shd, True, dw_zeroed=True)
+                Kn.conv2d_wgrad(desc, xd, dyd, dw_plain)
+                outs = [y, y0, dx, dw_pro, dw_plain]
+                if ys is not None:
+                    y3, sm = torch.empty(yr.shape, device="cuda"), torch.empty(x.shape, device="cuda")
+                    Kn.conv2d_fwd_addrelu(desc, xd, wd, None, y3, scd, shd, resd, None, None, sm)
+                    outs += [y3, sm]
+                torch.cuda.synchronize()
+                outs = [o.cpu().double() for o in outs]
+                refs = [yr.detach(), yr.detach(), xr.grad, wr.grad, w_plain.grad] + ([ys, xs.double()] if ys is not None else [])
+                errs = [rel_l2(o, r) for o, r in zip(outs, refs)]
+                assert max(errs) <= X3_TOL, (tag, errs)
+                st = stats.cpu().double()
+                assert (st[:, 0].sum(0) - outs[0].reshape(-1, co).sum(0)).abs().max() <= 1e-4 * float(yr.detach().abs().max()) * b * h * w, tag
+    finally:
+        for direction in (0, 4, 1, 2):
+            _lib.check(lib.dj_conv2d_tune_set(direction, desc, -1, 1), "tune_set")
+
+
+@pytest.mark.parametrize("archi", ["deconv", "ssd_custom"])
+def test_training_step_float32x3_meets_the_fp32_bar(archi, floatx):
+    """SSD300 training step under float32x3 against the fp64 oracle at the bar of the exact-fp32 mode -- predictions 1e-3
+    (max-norm), loss 1e-3 -- and, for the weight update (whose gradient at batch 2 is ill-conditioned in ANY fp32
+    arithmetic: tests/test_ssd_gpu.py holds the exact-fp32 mode to 1e-2 per well-conditioned tensor), 5e-3 rel-L2 over all
+    tensors together; the exact-fp32 mode's own figure is printed beside it (measured: 3.6e-4 against 1.6e-3)."""
+    from jpeg_detection_resnet_ssd_amd import workloads
+    from oracle import ssd_resnet_dct as oracle
+    floatx.clear_session()
+    model, sizes = workloads.build_ssd(archi)
+    x, y_true = workloads.synthetic_batch(archi, sizes, 2)
+    w0 = model.get_weights_dict()
+    wt = {k: torch.from_numpy(v).double() for k, v in w0.items()}
+    ref = oracle.ssd_training_step(wt, [torch.from_numpy(a).double() for a in x], torch.from_numpy(y_true).double(), archi,
+                                   lr=0.001, momentum=0.9)
+    den = sum(float(((ref["new_weights"][k] - wt[k]) ** 2).sum()) for k in w0 if k in ref["new_weights"])
+    got = {}
+    for mode in ("float32x3", "float32"):
+        if mode == "float32":
+            floatx.clear_session()              # (the same auto-generated layer names as the first build)
+        m = model if mode == "float32x3" else workloads.build_ssd(archi)[0]
+        assert m.set_weights_dict(w0, strict=True) == len(w0)
+        floatx.set_floatx(mode)
+        loss = m.train_on_batch(x, y_true)
+        torch.cuda.synchronize()
+        plan = m._plan(2, True, True)
+        assert plan.compute_mode == (3 if mode == "float32x3" else 0) and not plan.store16
+        y_pred = plan.outputs[0].buf.cpu().double()
+        floatx.set_floatx("float32")
+        e_pred = float((y_pred - ref["y_pred"]).abs().max()) / float(ref["y_pred"].abs().max())
+        e_loss = abs(loss - ref["loss"]) / abs(ref["loss"])
+        w1 = m.get_weights_dict()
+        num = sum(float(((torch.from_numpy(w1[k]).double() - ref["new_weights"][k]) ** 2).sum()) for k in w0 if k in ref["new_weights"])
+        got[mode] = (e_pred, e_loss, (num / den) ** 0.5)
+        print("%s %s: pred max-norm %.2e, loss %.2e, update rel-L2 %.2e" % (mode, archi, e_pred, e_loss, got[mode][2]))
+    e_pred, e_loss, e_upd = got["float32x3"]
+    assert e_pred <= 1e-3 and e_loss <= 1e-3, got
+    assert e_upd <= 5e-3 and got["float32"][2] <= 5e-3, got
