@@ -139,6 +139,9 @@ __device__ __forceinline__ void dj_split_store(short* dst, f32x4 v, int lo_off) 
 //     this for the fp32 kernels (NP 1 of dj_igemm_fast.h); here the counters say the kernels are bound by instruction ISSUE
 //     (rocprofv3, 1x1 256->1024 @38x38 forward: instructions issuing in 83 % of a SIMD's cycles, matrix pipe busy 18 %, 37 %
 //     of a wave's life waiting for data), and two thirds of the convolutions of a bottleneck block are 1x1.
+#ifndef DJ_H16_ILV
+#define DJ_H16_ILV 1
+#endif
 template <int BM, int BN, int AM, int BMD, int PRO, int PREC, int BK = 32, int PF = 1, int EPI = 0, int AT = 0, int BT = 0, int NP = 0>
 __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p) {
   static_assert(NP == 0 || PRO != 3, "NP: not with the residual-add prologue (which keeps row indices of its own)");
@@ -397,20 +400,17 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
     }
   };
 
-  // prologue in fp32, then ONE rounding per element, 8-byte LDS stores
-  auto store_tiles = [&](const Regs& R, short* sA, short* sB) {
+  auto store_a = [&](const Regs& R, short* sA, int j) {
     const ARaw(&ra)[NA] = R.ra;
-    const BRaw(&rb)[NB] = R.rb;
     const ARaw(&ra2)[PRO == 3 ? NA : 1] = R.ra2;
     const unsigned a_valid = R.a_valid;
     const f32x4 psc = R.psc, psh = R.psh, psc2 = R.psc2, psh2 = R.psh2;
     const int pro_c0 = R.pro_c0;
-#pragma unroll
-    for (int j = 0; j < NA; ++j) {
+    {
       short* dst = (AM != 2) ? sA + (ar0 + ARPP * j) * PA + 4 * ac : sA + ar0 * PA + 4 * (ac + 8 * j);
       if constexpr (A_COPY) {   // stored in the MFMA's type, no prologue: out-of-range pieces arrived as zeros
         *reinterpret_cast<u32x2*>(dst) = ra[j];
-        continue;
+        return;
       }
       f32x4 v = dj_raw_to_f32<AT>(ra[j]);
       if (PRO) {
@@ -441,8 +441,10 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
         *reinterpret_cast<dj_short4*>(dst) = dj_round4<PREC>(v);
       }
     }
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
+  };
+  auto store_b = [&](const Regs& R, short* sB, int j) {
+    const BRaw(&rb)[NB] = R.rb;
+    {
       short* dst = (BMD == 0) ? sB + (bkr0 + BKSTEP * j) * PB + 4 * bcn : sB + (br0 + RPP * j) * PB + 4 * bc;
       if constexpr (B_COPY)
         *reinterpret_cast<u32x2*>(dst) = rb[j];
@@ -451,6 +453,13 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
       else
         *reinterpret_cast<dj_short4*>(dst) = dj_round4<PREC>(dj_raw_to_f32<BT>(rb[j]));
     }
+  };
+  // prologue in fp32, then ONE rounding per element, 8-byte LDS stores
+  auto store_tiles = [&](const Regs& R, short* sA, short* sB) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) store_a(R, sA, j);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) store_b(R, sB, j);
   };
 
   // No accumulator clears: the first MFMA of every accumulator takes the constant 0 as its C operand (an inline constant
@@ -473,41 +482,47 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
     dj_tr4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dj_tr4 __attribute__((address_space(3)))*)(dj_lds_short*)(q + 4 * pitch));
     return dj_s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   };
-  auto compute = [&](auto first_tag, const short* sA, const short* sB, int s) {
-    constexpr bool FIRST = decltype(first_tag)::value;   // this MFMA starts its accumulator
-    dj_s16x8 fa[TM], fb[TN], fa_lo[PREC == 3 ? TM : 1], fb_lo[PREC == 3 ? TN : 1];
+  struct Frags {
+    dj_s16x8 a[TM], b[TN], a_lo[PREC == 3 ? TM : 1], b_lo[PREC == 3 ? TN : 1];
+  };
+  auto load_frags = [&](Frags& f, const short* sA, const short* sB, int s) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) fa[i] = frag(sA, Cfg::A_KC, kc_a, tr_a, PA, wm * TM + i, s);
+    for (int i = 0; i < TM; ++i) f.a[i] = frag(sA, Cfg::A_KC, kc_a, tr_a, PA, wm * TM + i, s);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) fb[j] = frag(sB, Cfg::B_KC, kc_b, tr_b, PB, wn * TN + j, s);
+    for (int j = 0; j < TN; ++j) f.b[j] = frag(sB, Cfg::B_KC, kc_b, tr_b, PB, wn * TN + j, s);
     if constexpr (PREC == 3) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa_lo[i] = frag(sA + Cfg::STAGE_H, Cfg::A_KC, kc_a, tr_a, PA, wm * TM + i, s);
+      for (int i = 0; i < TM; ++i) f.a_lo[i] = frag(sA + Cfg::STAGE_H, Cfg::A_KC, kc_a, tr_a, PA, wm * TM + i, s);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb_lo[j] = frag(sB + Cfg::STAGE_H, Cfg::B_KC, kc_b, tr_b, PB, wn * TN + j, s);
+      for (int j = 0; j < TN; ++j) f.b_lo[j] = frag(sB + Cfg::STAGE_H, Cfg::B_KC, kc_b, tr_b, PB, wn * TN + j, s);
     }
+  };
+  // one accumulator's share of a 16-deep slice: one MFMA, three for the split operands of PREC 3
+  auto mfma_unit = [&](bool first, const Frags& f, int i, int j) {
+    f32x16 c = acc[i][j];
+    if (first) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c[r] = 0.f;
+    }
+    if constexpr (PREC == 3) {
+      // the two small products first, the large one last
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dj_bf16x8, f.a_lo[i]), __builtin_bit_cast(dj_bf16x8, f.b[j]), c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dj_bf16x8, f.a[i]), __builtin_bit_cast(dj_bf16x8, f.b_lo[j]), c, 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dj_bf16x8, f.a[i]), __builtin_bit_cast(dj_bf16x8, f.b[j]), c, 0, 0, 0);
+    } else if constexpr (PREC == 1) {
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(dj_half8, f.a[i]), __builtin_bit_cast(dj_half8, f.b[j]), c, 0, 0, 0);
+    } else {
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dj_bf16x8, f.a[i]), __builtin_bit_cast(dj_bf16x8, f.b[j]), c, 0, 0, 0);
+    }
+  };
+  auto compute = [&](auto first_tag, const short* sA, const short* sB, int s) {
+    constexpr bool FIRST = decltype(first_tag)::value;   // this MFMA starts its accumulator
+    Frags f;
+    load_frags(f, sA, sB, s);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        f32x16 c = acc[i][j];
-        if (FIRST) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) c[r] = 0.f;
-        }
-        if constexpr (PREC == 3) {
-          // the two small products first, the large one last
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dj_bf16x8, fa_lo[i]), __builtin_bit_cast(dj_bf16x8, fb[j]), c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dj_bf16x8, fa[i]), __builtin_bit_cast(dj_bf16x8, fb_lo[j]), c, 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dj_bf16x8, fa[i]), __builtin_bit_cast(dj_bf16x8, fb[j]), c, 0, 0, 0);
-        } else
-        if (PREC == 1)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(dj_half8, fa[i]),
-                                                             __builtin_bit_cast(dj_half8, fb[j]), c, 0, 0, 0);
-        else
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dj_bf16x8, fa[i]),
-                                                              __builtin_bit_cast(dj_bf16x8, fb[j]), c, 0, 0, 0);
-      }
+      for (int j = 0; j < TN; ++j) mfma_unit(FIRST, f, i, j);
   };
 
   // two LDS stages: tile kt+1 is stored while tile kt is multiplied
@@ -519,6 +534,39 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
     short* nxt = smem + ((kt + 1) & 1) * STAGE;
     issue_loads(load_into, k_load, live);
     if (PF == 2) __builtin_amdgcn_sched_barrier(0);   // the loads stay up here, a whole step ahead of their LDS stores
+#if DJ_H16_ILV
+    {
+      // Interleaved K-step.  The matrix pipe takes 32 cycles per MFMA while the wave is free to issue 4-cycle vector
+      // instructions, but the compiler's schedule keeps the MFMAs of a slice together and the next tile's prologue /
+      // rounding / LDS stores in one long vector stretch during which the matrix pipe idles (and with one or two waves per
+      // SIMD nobody else fills it).  Here the order is pinned: after each accumulator's MFMA(s) comes a share of the next
+      // tile's pieces, the following slice's fragments are read a slice ahead.
+      constexpr int S = BK / 16, U = TM * TN, P = NA + NB;
+      constexpr int G0 = (PF == 2) ? 0 : (S * U) / 4;        // PF 1: the pieces were requested at the top of this step
+      Frags f[2];
+      load_frags(f[0], cur, cur + Cfg::A_H, 0);
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        if (s + 1 < S) load_frags(f[(s + 1) & 1], cur, cur + Cfg::A_H, s + 1);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          mfma_unit(FIRST && s == 0, f[s & 1], u / TN, u % TN);
+          const int g = s * U + u;
+          if (g >= G0) {
+            const int p0 = (g - G0) * P / (S * U - G0), p1 = (g - G0 + 1) * P / (S * U - G0);
+#pragma unroll
+            for (int q = p0; q < p1; ++q) {
+              if (q < NA) store_a(store_from, nxt, q);
+              else store_b(store_from, nxt + Cfg::A_H, q - NA);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();
+      return;
+    }
+#endif
     if (FIRST) compute(First{}, cur, cur + Cfg::A_H, 0);
 #pragma unroll
     for (int st = FIRST ? 1 : 0; st < BK / 32; ++st) compute(Later{}, cur, cur + Cfg::A_H, st);

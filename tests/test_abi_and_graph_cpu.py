@@ -240,10 +240,15 @@ def test_tuning_tables_follow_the_arithmetic_mode():
         assert half is not fp32 and key in fp32 and key in half
         K.set_floatx("bfloat16")
         assert engine._tune_db() is not fp32
+        K.set_floatx("float32x3")                            # fp32 products as three bf16 MFMAs: a table of its own
+        x3 = engine._tune_db()
+        assert K.floatx() == "float32x3" and x3 is not fp32 and x3 is not half and key in x3
+        with pytest.raises(ValueError):
+            K.set_floatx("float64")
     finally:
         K.set_floatx("float32")
     assert engine._tune_db() is fp32
-    for path in (engine._TUNE_DB, engine._TUNE_DB_LOWP):
+    for path in (engine._TUNE_DB, engine._TUNE_DB_LOWP, engine._TUNE_DB_X3):
         with open(path) as f:
             table = json.load(f)
         assert table["arch"] == "gfx950" and table["n_configs"] == ncfg

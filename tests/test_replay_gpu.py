@@ -322,6 +322,7 @@ CASES = [
     ("deconv_classifier_b64_f32", "cls:deconv", 64, "float32"),     # config 2
     ("ssd_custom_b32_f16", "ssd:ssd_custom", 32, "float16"),        # config 5 (late_concat_rfa_thinner backbone)
     ("up_sampling_b32_f16", "ssd:up_sampling", 32, "float16"),      # config 5 (up_sampling_rfa fusion)
+    ("deconv_ssd_b32_x3", "ssd:deconv", 32, "float32x3"),           # the bench workload in the split-bf16 fp32 arithmetic
 ]
 _SEEN = {}      # floatx -> launches already replayed in an earlier case of that mode
 
@@ -331,9 +332,14 @@ _SEEN = {}      # floatx -> launches already replayed in an earlier case of that
 # their storage rounding: 2^-11 per fp16 tensor read or written (activations), 2^-8 per bf16 tensor (gradients), i.e.
 # BatchNormalization's dz, read from a bf16 gradient and a fp16 z and stored as bf16, is bounded by 8e-3 like the GEMM
 # gradients.
+# float32x3 (fp32 tensors, three bf16 MFMAs per product, ~4e-6 rel-L2 per GEMM): held to the bounds of the exact-fp32 mode,
+# against the fp64 oracle; only the "natural scale" bound on the statistics sums, which is a rounding-level bound (3e-5 for
+# fp32 MFMA), widens to 1e-4.
 TOLS = {
     "float32": dict(y_max=TOL, y_l2=TOL, sum_max=TOL, stats_sq=TOL, stats_sum=TOL, dx_l2=TOL, dx_max=TOL, dw_l2=TOL, dw_max=TOL, dz_l2=TOL,
                     dgamma_l2=TOL, dbeta_l2=TOL, scale_max=TOL, shift_max=TOL, shortcut_l2=TOL, nat=3e-5),
+    "float32x3": dict(y_max=TOL, y_l2=TOL, sum_max=TOL, stats_sq=TOL, stats_sum=TOL, dx_l2=TOL, dx_max=TOL, dw_l2=TOL, dw_max=TOL, dz_l2=TOL,
+                      dgamma_l2=TOL, dbeta_l2=TOL, scale_max=TOL, shift_max=TOL, shortcut_l2=TOL, nat=1e-4),
     "float16": dict(y_max=None, y_l2=1.5e-3, sum_max=1.5e-3, stats_sq=3e-3, stats_sum=1.5e-3, dx_l2=8e-3, dx_max=None, dw_l2=8e-3, dw_max=None,
                     dz_l2=8e-3, dgamma_l2=8e-3, dbeta_l2=8e-3, scale_max=TOL, shift_max=TOL, shortcut_l2=8e-3, nat=1.5e-3),
 }
@@ -387,7 +393,7 @@ def test_every_distinct_launch_of_the_step_matches_the_oracle(name, kind, batch,
         plan.run_backward()
         torch.cuda.synchronize()
 
-        rp = Replay(lowp=(floatx != "float32"))
+        rp = Replay(lowp=(floatx not in ("float32", "float32x3")))
         rp.seen = _SEEN.setdefault(floatx, set())
         n_before = len(rp.seen)
         for lyr in model.layers:
