@@ -136,8 +136,12 @@ def cpu_baseline(archi, batch, budget_s=25.0):
                       "at batch %d; median step %.2f s" % (len(use), archi, batch, med)}
 
 
-DTYPE_NAME = {"float32": "f32", "float16": "f16/bf16-mfma+f32-acc", "bfloat16": "bf16-mfma+f32-acc",
-              "float32x3": "f32 tensors, f32 products as 3 bf16 MFMAs on hi/lo split operands (~4e-6 rel per GEMM), f32 acc"}
+DTYPE_NAME = {"float32": "f32 (fp32 tensors, fp32 accumulation; per layer the fp32 MFMA kernel or the split-bf16 kernel -- 6 bf16 MFMAs "
+                         "on hi/mid/lo operand pieces, dropped terms 2^-24 -- whichever the tuning table measured faster; both are "
+                         "1.4e-7..4.6e-7 rel-L2 from the fp64 oracle per GEMM, tests/test_x3_gpu.py)",
+              "float32_mfma": "f32 (fp32 MFMA instructions only)", "float16": "f16/bf16-mfma+f32-acc", "bfloat16": "bf16-mfma+f32-acc",
+              "float32x3": "f32 tensors, f32 products as 3 bf16 MFMAs on hi/lo split operands (~4e-6 rel per GEMM), f32 acc",
+              "float32x6": "f32 tensors, f32 products as 6 bf16 MFMAs on hi/mid/lo split operands (fp32-grade), f32 acc"}
 
 
 def run_workload(archi, floatx, batch, steps, warmup, rank=0, world=1):
@@ -199,7 +203,7 @@ def roofline_of(archi, floatx, batch, value, world, model, plan):
             "note": "whole-step algorithmic conv FLOPs (SURVEY 8(d) table) / step time, per GPU"}
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     for rnd in ("r03", "r02"):
-        traffic_file = os.path.join(prof, "%s_igemm_traffic%s.json" % (rnd, {"float32": "", "float32x3": "_x3"}.get(floatx, "_f16")))
+        traffic_file = os.path.join(prof, "%s_igemm_traffic%s.json" % (rnd, {"float32": "", "float32_mfma": "_mfma", "float32x3": "_x3", "float32x6": "_x6"}.get(floatx, "_f16")))
         if os.path.exists(traffic_file) and archi == "deconv" and batch == 32:
             # offline rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_f_hbm_traffic_pmc.md), bytes per launch
             with open(traffic_file) as f:
@@ -220,17 +224,43 @@ def roofline_of(archi, floatx, batch, value, world, model, plan):
                                    "algorithmic_gflop_per_step": k["flop"] / 1e9,
                                    "algorithmic_gbyte_per_step": k["bytes"] / 1e9,
                                    "algorithmic_gbyte_per_s": k["bytes"] / (k["total_ms"] * 1e-3) / 1e9}
-        if floatx == "float32x3":
-            # three bf16 MFMAs per fp32 product: the matrix pipe executes 3x the algorithmic FLOPs, at the bf16 rate
-            roof.update({"achieved": 3 * per_gpu_tflops, "peak": PEAK_F16_MFMA_TFLOPS, "frac": 3 * per_gpu_tflops / PEAK_F16_MFMA_TFLOPS,
-                         "note": "whole-step conv FLOPs x3 (each fp32 product = 3 bf16 MFMA products) / step time, per GPU, "
+        if floatx in ("float32x3", "float32x6"):
+            # three / six bf16 MFMAs per fp32 product: the matrix pipe executes 3x / 6x the algorithmic FLOPs, at the bf16 rate
+            nx = 3 if floatx == "float32x3" else 6
+            roof.update({"achieved": nx * per_gpu_tflops, "peak": PEAK_F16_MFMA_TFLOPS, "frac": nx * per_gpu_tflops / PEAK_F16_MFMA_TFLOPS,
+                         "note": "whole-step conv FLOPs x%d (each fp32 product = that many bf16 MFMA products) / step time, per GPU, " % nx +
                                  "against the dense bf16 MFMA peak; `useful_fp32` is the algorithmic rate next to the fp32 "
                                  "MFMA peak the exact mode is bounded by",
                          "useful_fp32": {"achieved": per_gpu_tflops, "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS,
                                          "ratio": per_gpu_tflops / PEAK_FP32_MFMA_TFLOPS, "kernel_family_tflops": ktf}})
-            roof["dominant_kernel"]["frac"] = 3 * ktf / PEAK_F16_MFMA_TFLOPS
-            roof["dominant_kernel"]["achieved"] = 3 * ktf
-        elif floatx != "float32":
+            roof["dominant_kernel"]["frac"] = nx * ktf / PEAK_F16_MFMA_TFLOPS
+            roof["dominant_kernel"]["achieved"] = nx * ktf
+        elif floatx == "float32":
+            # which launches of the plan run the split-bf16 kernels (upper half of the configuration indices)
+            from jpeg_detection_resnet_ssd_amd import _lib, engine
+            names = [n for n, _ in _lib.ConvDesc._fields_][:15]
+            prev = K.floatx()
+            K.set_floatx(floatx)
+            try:
+                n_mfma = _lib.load().dj_conv2d_tune_configs() // 2
+                f_split = f_all = 0.0
+                for direction, desc, _fn in plan.conv_calls:
+                    t = engine._TUNED._cur().get((direction,) + tuple(getattr(desc, n) for n in names))
+                    f_all += conv_flops(desc)
+                    if t is not None and t[1] >= n_mfma:
+                        f_split += conv_flops(desc)
+            finally:
+                K.set_floatx(prev)
+            share = f_split / max(f_all, 1.0)
+            p_split = PEAK_F16_MFMA_TFLOPS / 6.0
+            p_eff = 1.0 / ((1.0 - share) / PEAK_FP32_MFMA_TFLOPS + share / p_split)
+            roof["note"] += ("; `peak` is the dense fp32 MFMA peak (the dtype's peak, as in earlier rounds). %.0f %% of the conv FLOPs "
+                             "run on the split-bf16 kernels, whose matrix-pipe ceiling is 2500 / 6 = %.0f TFLOP/s of fp32 work: "
+                             "`matrix_pipe` prices the step against the ceiling of this kernel mix" % (100 * share, p_split))
+            roof["matrix_pipe"] = {"flop_share_split_bf16x6": share, "peak_split_bf16x6": p_split,
+                                   "peak_of_this_mix": p_eff, "frac_of_mix_peak": per_gpu_tflops / p_eff,
+                                   "kernel_family_frac_of_mix_peak": ktf / p_eff}
+        elif floatx != "float32_mfma":
             # reduced-precision MFMA: the GEMMs are ~16x cheaper, reading / writing the operands is what bounds the
             # family (2.4 TF of arithmetic per GB moved at these shapes against a machine balance of 2500 TF / 8 TB/s =
             # 312 FLOP/B): the roofline of this mode is HBM
@@ -248,8 +278,8 @@ def roofline_of(archi, floatx, batch, value, world, model, plan):
 # them too: config 3 and the two workloads of config 5 -- and the headline workload and config 3 in
 # the float32x3 arithmetic (fp32 tensors, 1e-3 parity bar of the exact mode met with two orders of magnitude to spare;
 # NOT the headline: `value` above stays the exact-fp32 MFMA rate)
-SECONDARY = [("deconv", "float32x3"), ("ssd_custom", "float32"), ("ssd_custom", "float32x3"), ("deconv", "float16"),
-             ("ssd_custom", "float16"), ("up_sampling", "float16")]
+SECONDARY = [("deconv", "float32_mfma"), ("deconv", "float32x3"), ("ssd_custom", "float32"), ("ssd_custom", "float32x3"),
+             ("deconv", "float16"), ("ssd_custom", "float16"), ("up_sampling", "float16")]
 
 
 def main(json_out=None):
@@ -259,7 +289,7 @@ def main(json_out=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--archi", default="deconv", choices=["deconv", "ssd_custom", "up_sampling"])
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (the reference trainer's batch_size)")
-    ap.add_argument("--floatx", default="float32", choices=["float32", "float16", "bfloat16", "float32x3"],
+    ap.add_argument("--floatx", default="float32", choices=["float32", "float32_mfma", "float16", "bfloat16", "float32x3", "float32x6"],
                     help="conv arithmetic: float32 = exact fp32 MFMA (the headline); float16 / bfloat16 = BASELINE config 5's "
                          "reduced-precision MFMA with fp32 master weights and accumulation (reported with its own dtype)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

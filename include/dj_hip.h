@@ -170,8 +170,15 @@ int dj_conv2d_nhwc_fwd_bn(const dj_conv2d_desc* d, const float* x, const float* 
  * launcher pick the branch-free buffer-load kernel whenever its alignment preconditions hold. */
 void dj_set_fast_path(int enable);
 
-/* Arithmetic of the implicit-GEMM kernels (BASELINE config 5, "fp16 MFMA"): 0 = exact fp32 MFMA (default; what every
- * parity claim at 1e-3 refers to); 1 = forward GEMMs round both operands to fp16 and gradient GEMMs (dgrad, wgrad,
+/* Arithmetic of the implicit-GEMM kernels: 0 = fp32 (default; what every parity claim at 1e-3 refers to): fp32 tensors,
+ * fp32 results, from whichever of two kernel families the tuning table names for a geometry -- v_mfma_f32_32x32x2_f32, or
+ * the split-bf16 kernels of mode 4 (measured against the fp64 oracle the two are equally far from it, 1.4e-7 .. 4.6e-7
+ * rel-L2 per GEMM; configuration indices [N, 2N) of dj_conv2d_tune_set select the latter);
+ * 5 = fp32 MFMA instructions only (indices [0, N); the behaviour of mode 0 before round 3's split kernels);
+ * 4 ("float32x6") = every product as six bf16 MFMAs on operands split into three bf16 pieces when they go to LDS
+ * (hi*hi + hi*mid + mid*hi + hi*lo + mid*mid + lo*hi; dropped: 2^-24 of a product), fp32 accumulation: fp32 results at
+ * 6/16 of the fp32 MFMA's matrix-pipe time; 3 ("float32x3") = two pieces, three MFMAs: ~4e-6 rel-L2 per GEMM;
+ * (BASELINE config 5, "fp16 MFMA":) 1 = forward GEMMs round both operands to fp16 and gradient GEMMs (dgrad, wgrad,
  * Conv2DTranspose forward) to bf16 as the fragments leave LDS, v_mfma_f32_32x32x8_{f16,bf16} with fp32 accumulation;
  * 2 = bf16 in every GEMM.  Tensors in HBM (activations, weights = the fp32 master copy, gradients, optimizer state)
  * stay fp32 in every mode.  Sets the process-wide default; returns the previous default. */
@@ -185,7 +192,8 @@ int dj_get_compute_mode(void);
  * 2 wgrad (+4: forward that takes BN statistics; 9: the input gradient of dj_conv2d_nhwc_dgrad_bnbwd, which runs other
  * kernels than a plain input gradient and is never split -- without an entry of its own it takes the tile shape of the
  * dir-1 entry); cfg in [0, dj_conv2d_tune_configs()) selects the tile shape
- * (128x128, 128x64, 64x64, 128x32), `splits` the split-K factor; cfg < 0 removes the override. */
+ * (128x128, 128x64, 64x64, 128x32) and schedule variant -- in mode 0 the count is twice that of the other modes, the upper
+ * half naming the split-bf16 (float32x6) variants --, `splits` the split-K factor; cfg < 0 removes the override. */
 int dj_conv2d_tune_configs(void);
 int dj_conv2d_tune_set(int dir, const dj_conv2d_desc* d, int cfg, int splits);
 int dj_conv2d_default_config(int dir, const dj_conv2d_desc* d, int* cfg, int* splits);

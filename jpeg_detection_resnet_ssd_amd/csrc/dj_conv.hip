@@ -25,7 +25,9 @@ extern "C" void dj_set_fast_path(int enable) { g_dj_allow_fast.store(enable != 0
 
 // Arithmetic mode.  0: fp32 MFMA everywhere (default).  1: forward GEMMs round their operands to fp16, gradient GEMMs
 // (dgrad, wgrad) to bf16 (gradients need the exponent range); 2: bf16 everywhere; 3 ("float32x3"): fp32 tensors, every
-// product as three bf16 MFMAs on hi / lo split operands (~2^-17 relative per product).  fp32 accumulation in all modes.
+// product as three bf16 MFMAs on hi / lo split operands (~2^-17 relative per product); 4 ("float32x6"): six MFMAs on
+// hi / mid / lo pieces (2^-24: fp32 results).  Mode 0 takes, per geometry, the fp32 MFMA kernel or the mode-4 kernel its
+// tuning entry names (both fp32 results); 5: fp32 MFMA kernels only.  fp32 accumulation in all modes.
 // A process-wide default (atomic) that a thread can override for its own launches: a plan lowered under one
 // mode keeps running in it whatever other models or threads of the process select (engine.Plan sets the override before
 // it launches).
@@ -34,12 +36,12 @@ static thread_local int tl_compute_mode = -1;
 int dj_compute_mode() { return tl_compute_mode >= 0 ? tl_compute_mode : g_default_compute_mode.load(std::memory_order_relaxed); }
 extern "C" int dj_set_compute_mode(int mode) {
   int prev = g_default_compute_mode.load(std::memory_order_relaxed);
-  if (mode >= 0 && mode <= 3) g_default_compute_mode.store(mode, std::memory_order_relaxed);
+  if (mode >= 0 && mode <= 5) g_default_compute_mode.store(mode, std::memory_order_relaxed);
   return prev;
 }
 extern "C" int dj_set_thread_compute_mode(int mode) {
   int prev = tl_compute_mode;
-  if (mode >= -1 && mode <= 3) tl_compute_mode = mode;
+  if (mode >= -1 && mode <= 5) tl_compute_mode = mode;
   return prev;
 }
 extern "C" int dj_get_compute_mode(void) { return dj_compute_mode(); }
@@ -118,12 +120,13 @@ static bool tune_lookup(int dir, const dj_conv2d_desc* d, int* cfg, int* splits)
   return true;
 }
 
-extern "C" int dj_conv2d_tune_configs(void) { return N_CFG; }
+// mode 0: [0, N_CFG) fp32 MFMA variants, [N_CFG, 2 N_CFG) the split-bf16 (float32x6) variants of the same indices
+extern "C" int dj_conv2d_tune_configs(void) { return dj_compute_mode() == 0 ? 2 * N_CFG : N_CFG; }
 
 // dir: 0 fwd, 1 dgrad, 2 wgrad, +4 when the forward takes BN statistics, 9 = input gradient that takes the
 // BatchNormalization backward statistics (dj_conv2d_nhwc_dgrad_bnbwd).  cfg < 0 removes the override.
 extern "C" int dj_conv2d_tune_set(int dir, const dj_conv2d_desc* d, int cfg, int splits) {
-  DJ_CHECK_ARG(d != nullptr && cfg < N_CFG && splits >= 1, "tune_set: bad arguments");
+  DJ_CHECK_ARG(d != nullptr && cfg < (dj_compute_mode() == 0 ? 2 * N_CFG : N_CFG) && splits >= 1, "tune_set: bad arguments");
   std::lock_guard<std::mutex> g(g_tune_mu);
   if (cfg < 0)
     g_tune.erase(tune_key(dir, d));

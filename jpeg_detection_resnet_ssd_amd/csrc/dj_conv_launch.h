@@ -139,8 +139,9 @@ static int launch_k2(const DjIgemmParams& p, int splits, hipStream_t s, int fast
 
 extern std::atomic<bool> g_dj_allow_fast;   // dj_conv.hip
 
-// 0: fp32 MFMA everywhere (default).  1: forward GEMMs round their operands to fp16, gradient GEMMs (dgrad, wgrad) to
-// bf16 (gradients need the exponent range); 2: bf16 everywhere.  fp32 accumulation and fp32 tensors in all modes.
+// 0: fp32 results (default; fp32 MFMA or split-bf16 kernel per tuning entry), 5: fp32 MFMA only.  1: forward GEMMs round
+// their operands to fp16, gradient GEMMs (dgrad, wgrad) to bf16 (gradients need the exponent range); 2: bf16 everywhere;
+// 3 / 4: fp32 products as three / six bf16 MFMAs on split operands.  fp32 accumulation in all modes.
 int dj_compute_mode();   // dj_conv.hip: the calling thread's override, else the process default
 
 // Preconditions of dj_igemm_fast_kernel (see its header comment).
@@ -169,7 +170,14 @@ int dj_launch_lowp(int cfg, const DjIgemmParams& p, int splits, hipStream_t s, i
 template <int AM, int BMD>
 int dj_launch_cfg(int cfg, const DjIgemmParams& p, int splits, hipStream_t s) {
   const int fast = fast_mode<AM, BMD>(p);
-  const int mode = dj_compute_mode();
+  int mode = dj_compute_mode();
+  if (mode == 5) mode = 0;                      // fp32 MFMA kernels only: its tables hold indices below N_CFG
+  if (cfg >= N_CFG) {
+    // mode 0, upper half of the index range: the split-bf16 kernel (fp32 tensors, fp32 results; dj_igemm_h16.h PREC 4)
+    // of that index -- where the branch-free kernels' preconditions do not hold, the fp32 variant of the same index
+    cfg -= N_CFG;
+    if (fast && mode == 0 && cfg < N_CFG) return dj_launch_lowp<AM, BMD>(cfg, p, splits, s, fast, 4);
+  }
   if (fast && mode != 0 && cfg >= 0 && cfg < N_CFG) {
     // A-mode 0 with B-mode 0 is the forward GEMM; everything else carries gradients
     return dj_launch_lowp<AM, BMD>(cfg, p, splits, s, fast, mode);

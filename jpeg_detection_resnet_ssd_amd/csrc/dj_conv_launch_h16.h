@@ -37,7 +37,9 @@ static int launch_h16_kernel(int smem_bytes, const DjIgemmParams& p, int splits,
 // dj_igemm_h16.h
 template <int BM, int BN, int AM, int BMD, int PREC, int BK, int PF, int AT, int BT>
 static int launch_h16(const DjIgemmParams& p, int splits, hipStream_t s, int fast) {
-  constexpr int SMEM_BYTES = DjH16Cfg<BM, BN, AM, BMD, BK>::SMEM_BYTES * (PREC == 3 ? 2 : 1);   // float32x3: a hi and a lo image per operand
+  // float32x3 / float32x6: two / three bf16 images per operand
+  constexpr int SMEM_BYTES = DjH16Cfg<BM, BN, AM, BMD, BK>::SMEM_BYTES * (PREC == 4 ? 3 : PREC == 3 ? 2 : 1);
+  static_assert(SMEM_BYTES <= 160 * 1024, "LDS of a CU");
   if (fast == 3) {
     if constexpr (AM == 0 && BMD == 0) {
       return launch_h16_kernel<BM, BN, AM, BMD, 3, PREC, BK, PF, AT, BT>(SMEM_BYTES, p, splits, s);
@@ -61,8 +63,12 @@ static int launch_h16_depth(const DjIgemmParams& p, int splits, hipStream_t s, i
   if constexpr (AM != 2) {
     // 64-deep K-steps where a step stays inside one filter tap and every K chunk is whole (DJ_H16_BK32=1: never)
     static const bool bk32 = getenv("DJ_H16_BK32") != nullptr;
-    if (deep && !bk32 && p.srcC % 64 == 0 && p.kchunk % 64 == 0)
-      return launch_h16<BM, BN, AM, BMD, PREC, 64, PF, AT, BT>(p, splits, s, fast);
+    // (float32x6: three images per operand -- a 64-deep stage pair of a 128-row tile does not fit the 160 KB of a CU)
+    constexpr bool fits = DjH16Cfg<BM, BN, AM, BMD, 64>::SMEM_BYTES * (PREC == 4 ? 3 : PREC == 3 ? 2 : 1) <= 160 * 1024;
+    if constexpr (fits) {
+      if (deep && !bk32 && p.srcC % 64 == 0 && p.kchunk % 64 == 0)
+        return launch_h16<BM, BN, AM, BMD, PREC, 64, PF, AT, BT>(p, splits, s, fast);
+    }
   }
   return launch_h16<BM, BN, AM, BMD, PREC, 32, PF, AT, BT>(p, splits, s, fast);
 }
@@ -97,18 +103,30 @@ static int launch_lowp_cfg(int cfg, const DjIgemmParams& p, int splits, hipStrea
   return launch_lowp<64, 64, AM, BMD, PREC, AT, BT>(p, splits, s, fast, deep, pf2);   // 64x64 and 128x32 requests
 }
 
+// fp32 tensors, split-bf16 arithmetic: instantiated per GEMM role in dj_conv_x*.hip
+template <int AM, int BMD>
+int dj_launch_split(int cfg, const DjIgemmParams& p, int splits, hipStream_t s, int fast, int mode);
+#ifdef DJ_SPLIT_UNIT
+template <int AM, int BMD>
+int dj_launch_split(int cfg, const DjIgemmParams& p, int splits, hipStream_t s, int fast, int mode) {
+  if (mode == 4) return launch_lowp_cfg<AM, BMD, 4, 0, 0>(cfg, p, splits, s, fast);
+  return launch_lowp_cfg<AM, BMD, 3, 0, 0>(cfg, p, splits, s, fast);
+}
+#endif
+
 // One instantiation per (GEMM role, storage types of A and B), each in a translation unit of its own (dj_conv_h*.hip).
 // Storage types that exist: activations fp16 (A of the forward GEMM and of the weight gradient), gradients bf16 (A of the
 // input gradients, B of the weight gradient); with 16-bit operands only the mixed mode 1 (fp16 forward / bf16 gradients).
 template <int AM, int BMD, int AT, int BT>
 int dj_launch_lowp_io(int cfg, const DjIgemmParams& p, int splits, hipStream_t s, int fast, int mode) {
   // A-mode 0 with B-mode 0 is the forward GEMM; everything else carries gradients (bf16: they need the exponent range)
-  if constexpr (AT == 0 && BT == 0) {     // float32x3: fp32 tensors, three bf16 MFMAs per product
-    if (mode == 3) return launch_lowp_cfg<AM, BMD, 3, AT, BT>(cfg, p, splits, s, fast);
-  }
-  if (mode == 3) {
-    dj_set_error("arithmetic mode 3 (float32x3) works on fp32 tensors");
-    return DJ_ERR_ARG;
+  if (mode >= 3) {   // float32x3 / float32x6: fp32 tensors, products as three / six bf16 MFMAs (units dj_conv_x*.hip)
+    if constexpr (AT == 0 && BT == 0) {
+      return dj_launch_split<AM, BMD>(cfg, p, splits, s, fast, mode);
+    } else {
+      dj_set_error("arithmetic modes 3 / 4 (float32x3 / float32x6) work on fp32 tensors");
+      return DJ_ERR_ARG;
+    }
   }
   if constexpr (AM == 0 && BMD == 0) {   // (fp16 variants are instantiated for the forward GEMM only)
     if (mode == 1) return launch_lowp_cfg<AM, BMD, 1, AT, BT>(cfg, p, splits, s, fast);

@@ -21,6 +21,11 @@
 // BatchNormalization(+ReLU) prologue in fp32 before the rounding, XCD-aware tile order, split-K) and the epilogue are
 // those of the fp32 kernel.
 //
+// PREC 4 ("float32x6", arithmetic mode 4): as PREC 3 below with THREE bf16 pieces per operand (24 significant bits: all of an
+// fp32 value) and six MFMAs per product -- hi*hi, hi*mid, mid*hi, hi*lo, mid*mid, lo*hi; the dropped terms are <= 2^-24 of
+// the product, the size of ONE fp32 rounding -- i.e. fp32 results on the bf16 matrix pipe at 6/16 of the fp32 MFMA's time.
+// Three LDS images per operand: K-steps of 32 only for the 128-row tiles.
+//
 // PREC 3 ("float32x3", arithmetic mode 3; round 3): fp32 tensors, fp32 RESULTS to ~2^-17, on the bf16 matrix pipe.  The fp32
 // MFMA of gfx950 runs at 157 TFLOP/s, the bf16 MFMA at 2500: an fp32 operand is split, when it goes to LDS, into the bf16
 // nearest to it (hi) and the bf16 nearest to what is left (lo) -- |x - hi - lo| <= 2^-18 |x| -- and a product is three MFMAs,
@@ -124,6 +129,22 @@ __device__ __forceinline__ void dj_split_store(short* dst, f32x4 v, int lo_off) 
   *reinterpret_cast<dj_short4*>(dst + lo_off) = dj_to_bf16x4(v - back);
 }
 
+__device__ __forceinline__ f32x4 dj_bf16x4_to_f32(dj_short4 h) {
+  return f32x4{__builtin_bit_cast(float, (unsigned)(unsigned short)h.x << 16), __builtin_bit_cast(float, (unsigned)(unsigned short)h.y << 16),
+               __builtin_bit_cast(float, (unsigned)(unsigned short)h.z << 16), __builtin_bit_cast(float, (unsigned)(unsigned short)h.w << 16)};
+}
+// float32x6: x = hi + mid + lo, each the bf16 nearest to what the ones before it leave (3 x 8 significant bits: what is left
+// after lo is <= 2^-24 |x|); the images sit lo_off elements apart
+__device__ __forceinline__ void dj_split_store3(short* dst, f32x4 v, int lo_off) {
+  const dj_short4 hi = dj_to_bf16x4(v);
+  const f32x4 r1 = v - dj_bf16x4_to_f32(hi);          // exact: hi agrees with v in its leading bits
+  const dj_short4 mid = dj_to_bf16x4(r1);
+  const f32x4 r2 = r1 - dj_bf16x4_to_f32(mid);        // exact
+  *reinterpret_cast<dj_short4*>(dst) = hi;
+  *reinterpret_cast<dj_short4*>(dst + lo_off) = mid;
+  *reinterpret_cast<dj_short4*>(dst + 2 * lo_off) = dj_to_bf16x4(r2);
+}
+
 // PRO: 0 plain A, 1 A*scale[c]+shift[c] (+ReLU) on in-bounds elements, 3 the residual-add prologue of the forward 1x1
 // convolutions, relu(A*scale+shift + A2*scale2+shift2), whose column-tile-0 workgroups also store that sum (fp32) to
 // p.sum_out (see dj_igemm_fast.h).  PREC: 1 fp16, 2 bf16.
@@ -146,14 +167,14 @@ template <int BM, int BN, int AM, int BMD, int PRO, int PREC, int BK = 32, int P
 __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p) {
   static_assert(NP == 0 || PRO != 3, "NP: not with the residual-add prologue (which keeps row indices of its own)");
   static_assert(EPI == 0 || (AM == 1 && BMD == 1), "BatchNormalization backward statistics: input-gradient GEMM only");
-  static_assert(PREC != 3 || (AT == 0 && BT == 0), "float32x3: fp32 tensors");
+  static_assert(PREC < 3 || (AT == 0 && BT == 0), "float32x3 / float32x6: fp32 tensors");
   constexpr int EA = AT ? 2 : 4, EB = BT ? 2 : 4;   // bytes per stored element
   using ARaw = typename DjRaw<AT>::type;
   using BRaw = typename DjRaw<BT>::type;
   // the piece goes from HBM to LDS as it is: stored in the MFMA's type, no prologue
-  constexpr bool A_COPY = (AT == PREC) && PRO == 0 && PREC != 3, B_COPY = (BT == PREC) && PREC != 3;
+  constexpr bool A_COPY = (AT == PREC) && PRO == 0 && PREC < 3, B_COPY = (BT == PREC) && PREC < 3;
   using Cfg = DjH16Cfg<BM, BN, AM, BMD, BK>;
-  constexpr int IMGS = (PREC == 3) ? 2 : 1;           // LDS images per operand: PREC 3 keeps a hi and a lo bf16 image
+  constexpr int IMGS = (PREC == 4) ? 3 : (PREC == 3) ? 2 : 1;   // LDS images per operand: the bf16 pieces of PREC 3 / 4
   constexpr int STAGE = Cfg::STAGE_H * IMGS;          // elements per LDS stage; the lo images sit Cfg::STAGE_H behind the hi ones
   constexpr int TM = Cfg::TM, TN = Cfg::TN, NA = Cfg::NA, NB = Cfg::NB;
   constexpr int PA = Cfg::PA, PB = Cfg::PB, KCH = Cfg::KCH, RPP = Cfg::RPP;
@@ -435,7 +456,9 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
                                                   rY, ok ? (int)(e * 2u) : (int)DJ_OOB, 0, 0);
         }
       }
-      if constexpr (PREC == 3) {
+      if constexpr (PREC == 4) {
+        dj_split_store3(dst, v, Cfg::STAGE_H);
+      } else if constexpr (PREC == 3) {
         dj_split_store(dst, v, Cfg::STAGE_H);
       } else {
         *reinterpret_cast<dj_short4*>(dst) = dj_round4<PREC>(v);
@@ -448,6 +471,8 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
       short* dst = (BMD == 0) ? sB + (bkr0 + BKSTEP * j) * PB + 4 * bcn : sB + (br0 + RPP * j) * PB + 4 * bc;
       if constexpr (B_COPY)
         *reinterpret_cast<u32x2*>(dst) = rb[j];
+      else if constexpr (PREC == 4)
+        dj_split_store3(dst, dj_raw_to_f32<BT>(rb[j]), Cfg::STAGE_H);
       else if constexpr (PREC == 3)
         dj_split_store(dst, dj_raw_to_f32<BT>(rb[j]), Cfg::STAGE_H);
       else
@@ -483,18 +508,24 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
     return dj_s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   };
   struct Frags {
-    dj_s16x8 a[TM], b[TN], a_lo[PREC == 3 ? TM : 1], b_lo[PREC == 3 ? TN : 1];
+    dj_s16x8 a[TM], b[TN], a_lo[PREC >= 3 ? TM : 1], b_lo[PREC >= 3 ? TN : 1], a_l2[PREC == 4 ? TM : 1], b_l2[PREC == 4 ? TN : 1];
   };
   auto load_frags = [&](Frags& f, const short* sA, const short* sB, int s) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) f.a[i] = frag(sA, Cfg::A_KC, kc_a, tr_a, PA, wm * TM + i, s);
 #pragma unroll
     for (int j = 0; j < TN; ++j) f.b[j] = frag(sB, Cfg::B_KC, kc_b, tr_b, PB, wn * TN + j, s);
-    if constexpr (PREC == 3) {
+    if constexpr (PREC >= 3) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) f.a_lo[i] = frag(sA + Cfg::STAGE_H, Cfg::A_KC, kc_a, tr_a, PA, wm * TM + i, s);
 #pragma unroll
       for (int j = 0; j < TN; ++j) f.b_lo[j] = frag(sB + Cfg::STAGE_H, Cfg::B_KC, kc_b, tr_b, PB, wn * TN + j, s);
+    }
+    if constexpr (PREC == 4) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) f.a_l2[i] = frag(sA + 2 * Cfg::STAGE_H, Cfg::A_KC, kc_a, tr_a, PA, wm * TM + i, s);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) f.b_l2[j] = frag(sB + 2 * Cfg::STAGE_H, Cfg::B_KC, kc_b, tr_b, PB, wn * TN + j, s);
     }
   };
   // one accumulator's share of a 16-deep slice: one MFMA, three for the split operands of PREC 3
@@ -504,7 +535,19 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
 #pragma unroll
       for (int r = 0; r < 16; ++r) c[r] = 0.f;
     }
-    if constexpr (PREC == 3) {
+    if constexpr (PREC == 4) {
+      // hi*hi + (hi*mid + mid*hi) + (hi*lo + mid*mid + lo*hi): every term down to 2^-16 of the product, smallest first;
+      // mid*lo, lo*mid (2^-24) and lo*lo are dropped -- what fp32 rounding loses in one accumulation
+      auto mm = [](dj_s16x8 x, dj_s16x8 y, f32x16 acc_) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dj_bf16x8, x), __builtin_bit_cast(dj_bf16x8, y), acc_, 0, 0, 0);
+      };
+      c = mm(f.a_l2[i], f.b[j], c);
+      c = mm(f.a[i], f.b_l2[j], c);
+      c = mm(f.a_lo[i], f.b_lo[j], c);
+      c = mm(f.a_lo[i], f.b[j], c);
+      c = mm(f.a[i], f.b_lo[j], c);
+      acc[i][j] = mm(f.a[i], f.b[j], c);
+    } else if constexpr (PREC == 3) {
       // the two small products first, the large one last
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dj_bf16x8, f.a_lo[i]), __builtin_bit_cast(dj_bf16x8, f.b[j]), c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dj_bf16x8, f.a[i]), __builtin_bit_cast(dj_bf16x8, f.b_lo[j]), c, 0, 0, 0);

@@ -22,7 +22,7 @@ def image_data_format():
     return "channels_last"
 
 
-_FLOATX = {0: "float32", 1: "float16", 2: "bfloat16", 3: "float32x3"}
+_FLOATX = {0: "float32", 1: "float16", 2: "bfloat16", 3: "float32x3", 4: "float32x6", 5: "float32_mfma"}
 
 
 def floatx():
@@ -37,7 +37,11 @@ def set_floatx(value):
     stay fp32 tensors (unlike Keras, which would also store float16 variables).  'bfloat16': bf16 in every GEMM.
     'float32x3' (no Keras counterpart): fp32 tensors and fp32-grade results (~1e-5 relative per product), every product
     as three bf16 MFMAs on operands split into a high and a low bf16 half when they go to LDS.
-    'float32' restores the exact-fp32 MFMA path every 1e-3 parity claim refers to."""
+    'float32x6': three bf16 pieces per operand (all 24 significant bits) and six MFMAs per product -- what is dropped is
+    2^-24 of a product, the size of one fp32 rounding: fp32 results, on the bf16 matrix pipe.
+    'float32' (default): fp32 tensors and fp32 results -- per geometry the fp32 MFMA kernel or the float32x6 kernel,
+    whichever the tuning table measured faster (equally far from the fp64 oracle); what every 1e-3 parity claim refers to.
+    'float32_mfma': fp32 MFMA instructions only (the default before the split kernels existed)."""
     from .. import _lib
     modes = {v: k for k, v in _FLOATX.items()}
     if value not in modes:

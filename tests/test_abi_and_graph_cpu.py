@@ -230,12 +230,14 @@ def test_tuning_tables_follow_the_arithmetic_mode():
     from jpeg_detection_resnet_ssd_amd import _lib, engine
     from jpeg_detection_resnet_ssd_amd.keras import backend as K
     lib = _lib.load()
-    ncfg = lib.dj_conv2d_tune_configs()
+    ncfg = lib.dj_conv2d_tune_configs()                      # 'float32': fp32 MFMA variants + their split-bf16 twins
+    assert ncfg % 2 == 0
     key = "0,32,10,10,2048,10,10,1024,3,3,1,1,6,6,6,6"      # fc6 forward, batch 32
     try:
         assert K.floatx() == "float32"
         fp32 = engine._tune_db()
         K.set_floatx("float16")
+        assert lib.dj_conv2d_tune_configs() == ncfg // 2
         half = engine._tune_db()
         assert half is not fp32 and key in fp32 and key in half
         K.set_floatx("bfloat16")
@@ -243,15 +245,21 @@ def test_tuning_tables_follow_the_arithmetic_mode():
         K.set_floatx("float32x3")                            # fp32 products as three bf16 MFMAs: a table of its own
         x3 = engine._tune_db()
         assert K.floatx() == "float32x3" and x3 is not fp32 and x3 is not half and key in x3
+        K.set_floatx("float32x6")
+        assert K.floatx() == "float32x6" and engine._tune_db() is not fp32
+        K.set_floatx("float32_mfma")                         # fp32 MFMA instructions only: the table measured over those
+        mfma = engine._tune_db()
+        assert mfma is not fp32 and key in mfma and lib.dj_conv2d_tune_configs() == ncfg // 2
+        assert all(v[0] < ncfg // 2 for v in mfma.values())
         with pytest.raises(ValueError):
             K.set_floatx("float64")
     finally:
         K.set_floatx("float32")
     assert engine._tune_db() is fp32
-    for path in (engine._TUNE_DB, engine._TUNE_DB_LOWP, engine._TUNE_DB_X3):
+    for path in (engine._TUNE_DB, engine._TUNE_DB_MFMA, engine._TUNE_DB_LOWP, engine._TUNE_DB_X3):
         with open(path) as f:
             table = json.load(f)
-        assert table["arch"] == "gfx950" and table["n_configs"] == ncfg
+        assert table["arch"] == "gfx950" and table["n_configs"] == (ncfg if path == engine._TUNE_DB else ncfg // 2)
         for k, v in table["entries"].items():
             assert len(k.split(",")) == 16 and len(v) in (3, 4), k
             assert 0 <= v[0] < ncfg and v[1] >= 1, k

@@ -7,6 +7,8 @@ python bench.py --steps 30 --warmup 5 > $O/r3z_bench.json 2> $O/r3z_bench.err ||
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r3z_prof2 -- python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-secondary > $O/r3z_prof2.json 2> $O/r3z_prof2.err || exit 1
 DJ_SIDE_WGRAD=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r3z_prof1 -- python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-secondary > $O/r3z_prof1.json 2> $O/r3z_prof1.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/r3z_prof_mfma -- python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-secondary --floatx float32_mfma > $O/r3z_prof_mfma.json 2> $O/r3z_prof_mfma.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/r3z_prof_x3 -- python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-secondary --floatx float32x3 > $O/r3z_prof_x3.json 2> $O/r3z_prof_x3.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r3z_prof16 -- python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-secondary --floatx float16 > $O/r3z_prof16.json 2> $O/r3z_prof16.err || exit 1
 DJ_SIDE_WGRAD=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r3z_prof16_1 -- python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-secondary --floatx float16 > $O/r3z_prof16_1.json 2> $O/r3z_prof16_1.err || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/r3z_cal_fetch -- python $R/tools/pmc_calibrate.py > /dev/null 2> $O/r3z_cal_fetch.err || exit 1
@@ -23,4 +25,6 @@ python tools/pmc_traffic.py $(find $O/r3z_fetch -name '*counter_collection.csv' 
 python tools/pmc_traffic.py $(find $O/r3z_fetch16 -name '*counter_collection.csv' | head -1) $(find $O/r3z_write16 -name '*counter_collection.csv' | head -1) $O/r3z_igemm_traffic_f16.json $3 $4 > $O/r3z_traffic16.txt
 python tools/profile_layers.py deconv 32 float16 > $O/r3z_layers_f16.txt 2>&1
 python tools/profile_layers.py deconv 32 float32 > $O/r3z_layers_f32.txt 2>&1
+python tools/profile_layers.py deconv 32 float32_mfma > $O/r3z_layers_mfma.txt 2>&1
+python tools/profile_layers.py deconv 32 float32x3 > $O/r3z_layers_x3.txt 2>&1
 echo done

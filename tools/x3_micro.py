@@ -1,5 +1,5 @@
 """float32x3 against the exact-fp32 kernels on representative layers of the SSD300 step: best tile variant (and split-K for
-the weight gradient) of each mode, TFLOP/s of useful fp32 work.   python tools/x3_micro.py [fwd|dgrad|wgrad|all]"""
+the weight gradient) of each mode, TFLOP/s of useful fp32 work.   python tools/x3_micro.py [fwd|dgrad|wgrad|all] [float32x3|float32x6]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -20,6 +20,7 @@ lib = _lib.load()
 dev = torch.device("cuda:0")
 ncfg = lib.dj_conv2d_tune_configs()
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
+X = sys.argv[2] if len(sys.argv) > 2 else "float32x3"      # or float32x6
 
 
 def timeit(fn, iters=6):
@@ -52,7 +53,7 @@ for name, b, h, w, ci, co, k in SHAPES:
         if which not in ("all", dname):
             continue
         best = {}
-        for mode in ("float32", "float32x3"):
+        for mode in ("float32", X):
             KB.set_floatx(mode)
             res = []
             for cfg in range(ncfg):
@@ -67,8 +68,8 @@ for name, b, h, w, ci, co, k in SHAPES:
             best[mode] = min(res)
             t = tot.setdefault((dname, mode), [0.0, 0.0]); t[0] += best[mode][0]; t[1] += flop
         KB.set_floatx("float32")
-        a, c = best["float32"], best["float32x3"]
-        print("%-32s %-6s fp32 %.3f ms %6.1f TF (cfg %d/%d) | x3 %.3f ms %6.1f TF (cfg %d/%d)  x%.2f"
+        a, c = best["float32"], best[X]
+        print("%-32s %-6s fp32 %.3f ms %6.1f TF (cfg %d/%d) | split %.3f ms %6.1f TF (cfg %d/%d)  x%.2f"
               % (name, dname, a[0], flop / a[0] / 1e9, a[1], a[2], c[0], flop / c[0] / 1e9, c[1], c[2], a[0] / c[0]), flush=True)
 for (dname, mode), (t, f) in sorted(tot.items()):
     print("%s %s: %.3f ms, %.1f TF" % (dname, mode, t, f / t / 1e9))
