@@ -60,12 +60,18 @@ static int launch_h16(const DjIgemmParams& p, int splits, hipStream_t s, int fas
 
 template <int BM, int BN, int AM, int BMD, int PREC, int PF, int AT, int BT>
 static int launch_h16_depth(const DjIgemmParams& p, int splits, hipStream_t s, int fast, bool deep) {
-  if constexpr (AM != 2) {
-    // 64-deep K-steps where a step stays inside one filter tap and every K chunk is whole (DJ_H16_BK32=1: never)
-    static const bool bk32 = getenv("DJ_H16_BK32") != nullptr;
-    // (float32x6: three images per operand -- a 64-deep stage pair of a 128-row tile does not fit the 160 KB of a CU)
-    constexpr bool fits = DjH16Cfg<BM, BN, AM, BMD, 64>::SMEM_BYTES * (PREC == 4 ? 3 : PREC == 3 ? 2 : 1) <= 160 * 1024;
-    if constexpr (fits) {
+  static const bool bk32 = getenv("DJ_H16_BK32") != nullptr;   // DJ_H16_BK32=1: 32-deep K-steps only
+  if constexpr (PREC == 4 && BM == 128) {
+    // float32x6, 128-row tiles: three images of a 64-deep stage pair exceed the 160 KB of a CU, and those of a 32-deep one
+    // (92-120 KB) leave room for ONE workgroup = one wave per SIMD, with nobody to issue while it waits (counters: matrix
+    // pipe 50 % busy, 44 % of the wave's cycles waiting).  The "deep" indices name 16-deep K-steps instead: 56-74 KB, two
+    // workgroups per CU -- all three GEMM roles.
+    if (deep && !bk32 && p.srcC % 16 == 0 && p.kchunk % 16 == 0)
+      return launch_h16<BM, BN, AM, BMD, PREC, 16, PF, AT, BT>(p, splits, s, fast);
+  } else if constexpr (AM != 2) {
+    // 64-deep K-steps where a step stays inside one filter tap and every K chunk is whole
+    constexpr int IMGS = (PREC == 4 ? 3 : PREC == 3 ? 2 : 1);
+    if constexpr (DjH16Cfg<BM, BN, AM, BMD, 64>::SMEM_BYTES * IMGS <= 160 * 1024) {
       if (deep && !bk32 && p.srcC % 64 == 0 && p.kchunk % 64 == 0)
         return launch_h16<BM, BN, AM, BMD, PREC, 64, PF, AT, BT>(p, splits, s, fast);
     }

@@ -98,13 +98,13 @@ __device__ __forceinline__ f32x4 dj_raw_to_f32(typename DjRaw<DT>::type v) {
 
 template <int BM, int BN, int AM, int BMD, int BK = 32>
 struct DjH16Cfg {
-  static_assert(BK == 32 || (BK == 64 && AM != 2), "64-deep K-steps: forward / input gradient only");
+  static_assert(BK == 32 || BK == 16 || (BK == 64 && AM != 2), "64-deep K-steps: forward / input gradient only");
   static constexpr int TM = BM / 64, TN = BN / 64;   // 4 waves as 2 x 2
   static constexpr bool A_KC = (AM != 2), B_KC = (BMD == 1);
   // k-contiguous operands: a row of a K-step is KCH 16-byte chunks of four fp32; the 256 threads cover RPP rows per pass
   static constexpr int KCH = BK / 4, RPP = 256 / KCH;
   // the other layout ([k][cols], four columns per thread): 1024 / cols k rows per pass
-  static constexpr int NA = A_KC ? BM / RPP : BM / 32;   // 16-byte loads per thread and K-step
+  static constexpr int NA = A_KC ? BM / RPP : BK * BM / 1024;   // 16-byte loads per thread and K-step
   static constexpr int NB = B_KC ? BN / RPP : BK * BN / 1024;
   static constexpr int PA = A_KC ? BK + 8 : BM + 32, PB = B_KC ? BK + 8 : BN + 32;   // pitches, in 16-bit elements
   static constexpr int A_H = (A_KC ? BM : BK) * PA, B_H = (B_KC ? BN : BK) * PB;
@@ -207,7 +207,9 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
   const bool store_sum = (PRO == 3) && p.sum_out != nullptr && tile_n == 0;
 
   // ---------------- per-thread staging state (as in dj_igemm_fast.h) ----------------
-  const int ac = (AM != 2) ? tid % KCH : tid & 7, ar0 = (AM != 2) ? tid / KCH : tid >> 3;
+  // (weight gradient: a thread holds pixel row tid / ACG of the K-step and the 4-column chunks ac, ac + ACG, ...)
+  constexpr int ACG = (AM != 2) ? KCH : 256 / BK;
+  const int ac = tid % ACG, ar0 = tid / ACG;
   constexpr int ARPP = (AM != 2) ? RPP : 32;   // A rows between a thread's loads
   constexpr int BKSTEP = 1024 / BN;
   const int bcn = tid % (BN / 4), bkr0 = tid / (BN / 4);
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
   } else {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      int mm = m0 + 4 * (ac + 8 * i);
+      int mm = m0 + 4 * (ac + ACG * i);
       a2_ok[i] = mm < p.M;
       int tap = mm / p.srcC;
       a2_c[i] = mm - tap * p.srcC;
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
     const f32x4 psc = R.psc, psh = R.psh, psc2 = R.psc2, psh2 = R.psh2;
     const int pro_c0 = R.pro_c0;
     {
-      short* dst = (AM != 2) ? sA + (ar0 + ARPP * j) * PA + 4 * ac : sA + ar0 * PA + 4 * (ac + 8 * j);
+      short* dst = (AM != 2) ? sA + (ar0 + ARPP * j) * PA + 4 * ac : sA + ar0 * PA + 4 * (ac + ACG * j);
       if constexpr (A_COPY) {   // stored in the MFMA's type, no prologue: out-of-range pieces arrived as zeros
         *reinterpret_cast<u32x2*>(dst) = ra[j];
         return;
