@@ -195,7 +195,17 @@ def _tune_db():
         if path != "0" and os.path.exists(path):
             import json
             with open(path) as f:
-                _DB[mode] = json.load(f).get("entries", {})
+                table = json.load(f)
+            _DB[mode] = table.get("entries", {})
+            if mode == 4 and path == _TUNE_DB_X3 and os.path.exists(_TUNE_DB):
+                # 'float32x6' everywhere: no table of its own ships -- the default mode's table holds the measured x6
+                # choice wherever an x6 kernel won (upper half of its index range); the float32x3 table covers the rest
+                with open(_TUNE_DB) as f:
+                    both = json.load(f)
+                half = int(both.get("n_configs", 0)) // 2
+                for key, v in both.get("entries", {}).items():
+                    if half and v[0] >= half:
+                        _DB[mode][key] = [v[0] - half] + list(v[1:])
     return _DB[mode]
 
 
