@@ -144,6 +144,28 @@ DTYPE_NAME = {"float32": "f32 (fp32 tensors, fp32 accumulation; per layer the fp
               "float32x6": "f32 tensors, f32 products as 6 bf16 MFMAs on hi/mid/lo split operands (fp32-grade), f32 acc"}
 
 
+def build_classifier(archi, batch, seed=1234):
+    """BASELINE config 2: the ResNet50-DCT classifier (`ResNet50Custom`, classification_part/.../resnet_dct.py:317-452) with
+    the classification trainer's optimizer and loss (config/resnet/config_file.py:58-65), synthetic 224x224 JPEG-DCT
+    inputs (Y 28x28x64, chroma 14x14) and one-hot ImageNet labels."""
+    from jpeg_detection_resnet_ssd_amd.keras import backend as K
+    from jpeg_detection_resnet_ssd_amd.keras.optimizers import SGD
+    from jpeg_detection_resnet_ssd_amd.vgg_jpeg_keras.networks.resnet_dct import ResNet50Custom
+    K.clear_session()
+    K.set_random_seed(42)
+    model = ResNet50Custom(weights=None, archi=archi)
+    model.compile(optimizer=SGD(lr=0.1, momentum=0.9, decay=1e-4, nesterov=True), loss="categorical_crossentropy")
+    rng = np.random.default_rng(seed)
+    x = [rng.normal(0, 30, (batch,) + tuple(int(d) for d in t.shape[1:])).astype(np.float32) for t in model.inputs]
+    y = np.eye(1000, dtype=np.float32)[rng.integers(0, 1000, batch)]
+    return model, (x if len(x) > 1 else x[0]), y
+
+
+def plan_gflop_per_image(plan, batch):
+    """Algorithmic conv FLOPs (forward + both gradients) of one training step of `plan`, per image."""
+    return sum(conv_flops(desc) for _d, desc, _f in plan.conv_calls) / batch / 1e9
+
+
 def run_workload(archi, floatx, batch, steps, warmup, rank=0, world=1):
     """Build the SSD300 training workload `archi` under arithmetic mode `floatx`, run `warmup` untimed and `steps` timed
     training steps on a resident batch (barrier + synchronize on both sides, max over ranks) -> (elapsed seconds, last
@@ -154,13 +176,17 @@ def run_workload(archi, floatx, batch, steps, warmup, rank=0, world=1):
     prev = K.floatx()
     K.set_floatx(floatx)
     try:
-        model, sizes = workloads.build_ssd(archi)
+        if archi.startswith("cls:"):
+            model, x, y = build_classifier(archi[4:], batch, seed=1234 + rank)
+        else:
+            model, sizes = workloads.build_ssd(archi)
         model._ensure_params()
         if torch.distributed.is_initialized():
             dp = djdist.DataParallel(model)
             dp.broadcast_weights(0)
         # rank r draws its own shard of the global batch (data seed 1234 + r)
-        x, y = workloads.synthetic_batch(archi, sizes, batch, seed=1234 + rank, fast=True)
+        if not archi.startswith("cls:"):
+            x, y = workloads.synthetic_batch(archi, sizes, batch, seed=1234 + rank, fast=True)
         plan = model._plan(batch, True, True)
         model._upload(plan, x, y)
         torch.cuda.synchronize()
@@ -196,7 +222,7 @@ def roofline_of(archi, floatx, batch, value, world, model, plan):
     timed launch by launch with HIP events (one extra step)."""
     from jpeg_detection_resnet_ssd_amd import workloads
     from jpeg_detection_resnet_ssd_amd.keras import backend as K
-    gflop = workloads.TRAIN_GFLOP_PER_IMAGE[archi]
+    gflop = workloads.TRAIN_GFLOP_PER_IMAGE[archi] if archi in workloads.TRAIN_GFLOP_PER_IMAGE else plan_gflop_per_image(plan, batch)
     per_gpu_tflops = value * gflop / 1e3 / world
     roof = {"bound": "mfma", "achieved": per_gpu_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": per_gpu_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
@@ -279,6 +305,7 @@ def roofline_of(archi, floatx, batch, value, world, model, plan):
 # instructions only (what `value` measured in rounds 1-2) and in the float32x3 arithmetic (fp32 tensors, ~4e-6 per GEMM:
 # inside the 1e-3 parity bar but not an fp32 arithmetic, hence never the headline)
 SECONDARY = [("deconv", "float32_mfma"), ("deconv", "float32x3"), ("ssd_custom", "float32"), ("ssd_custom", "float32x3"),
+             ("cls:deconv", "float32"),      # config 2: the ResNet50-DCT classifier, batch 64
              ("deconv", "float16"), ("ssd_custom", "float16"), ("up_sampling", "float16")]
 
 
@@ -341,13 +368,19 @@ def main(json_out=None):
         sec = []
         for archi, floatx in SECONDARY:
             steps = min(args.steps, 20)
-            el, ls, m2, p2 = run_workload(archi, floatx, args.batch, steps, min(args.warmup, 3))
-            v = args.batch * steps / el
-            sec.append({"config": {"workload": "SSD300 ResNet50-DCT '%s' archi, %d images/GPU" % (archi, args.batch),
-                                   "archi": archi, "floatx": floatx, "train_gflop_per_image": workloads.TRAIN_GFLOP_PER_IMAGE[archi],
+            b2 = 64 if archi.startswith("cls:") else args.batch
+            el, ls, m2, p2 = run_workload(archi, floatx, b2, steps, min(args.warmup, 3))
+            v = b2 * steps / el
+            if archi.startswith("cls:"):
+                what = ("ResNet50-DCT classifier '%s' archi (BASELINE config 2), %d images/GPU, 224x224 JPEG-DCT inputs, "
+                        "categorical cross-entropy, Nesterov SGD" % (archi[4:], b2))
+                gf = plan_gflop_per_image(p2, b2)
+            else:
+                what, gf = "SSD300 ResNet50-DCT '%s' archi, %d images/GPU" % (archi, b2), workloads.TRAIN_GFLOP_PER_IMAGE[archi]
+            sec.append({"config": {"workload": what, "archi": archi, "floatx": floatx, "train_gflop_per_image": gf,
                                    "last_loss": ls},
                         "value": v, "unit": "images/sec", "ms_per_step": 1e3 * el / steps, "steps": steps,
-                        "dtype": DTYPE_NAME[floatx], "roofline": roofline_of(archi, floatx, args.batch, v, 1, m2, p2)})
+                        "dtype": DTYPE_NAME[floatx], "roofline": roofline_of(archi, floatx, b2, v, 1, m2, p2)})
             print("secondary %s %s: %.1f img/s (%.2f ms/step)" % (archi, floatx, v, 1e3 * el / steps), file=sys.stderr,
                   flush=True)
             del m2, p2
