@@ -24,6 +24,42 @@ def _free_port():
 
 
 def _rank_main(rank, world, port, out):
+    try:
+        _rank_body(rank, world, port, out)
+    except BaseException:      # the parent must hear about it: the other rank is now stuck in a collective
+        import traceback
+        out.put(("error", rank, traceback.format_exc()))
+        raise
+
+
+def _collect(procs, out, n, seconds=300):
+    """Results of `n` child processes; fails as soon as a child reports an exception or dies without a result (instead of
+    waiting out a collective that will never complete)."""
+    import queue
+    import time
+    res, t0 = [], time.time()
+    while len(res) < n:
+        try:
+            item = out.get(timeout=2)
+        except queue.Empty:
+            dead = [p for p in procs if not p.is_alive() and p.exitcode not in (0, None)]
+            if dead or time.time() - t0 > seconds:
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                pytest.fail("data-parallel child processes: exit codes %s after %.0f s, %d of %d results"
+                            % ([p.exitcode for p in procs], time.time() - t0, len(res), n))
+            continue
+        if item[0] == "error":
+            for p in procs:
+                if p.is_alive():
+                    p.terminate()
+            pytest.fail("rank %d raised:\n%s" % (item[1], item[2]))
+        res.append(item)
+    return res
+
+
+def _rank_body(rank, world, port, out):
     # On a box with at least `world` cards the checks run over RCCL, one GPU per rank, without anybody setting anything
     # (VERDICT r2 item 14: a driver run on a multi-GPU box must not silently fall back); on a one-GPU box both ranks
     # share card 0 and the transport is gloo.  DJ_TEST_DP_BACKEND / DJ_TEST_DP_GPUS override the detection.
@@ -64,7 +100,7 @@ def test_two_rank_step_matches_gradient_averaging(cuda, monkeypatch):
     procs = [ctx.Process(target=_rank_main, args=(r, 2, port, out)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([out.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    res = sorted(_collect(procs, out, len(procs)), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -111,6 +147,15 @@ def test_two_rank_step_matches_gradient_averaging(cuda, monkeypatch):
 
 
 def _one_rank_rccl_main(port, out):
+    try:
+        _one_rank_rccl_body(port, out)
+    except BaseException:
+        import traceback
+        out.put(("error", 0, traceback.format_exc()))
+        raise
+
+
+def _one_rank_rccl_body(port, out):
     """Child process: a 1-rank RCCL communicator (backend "nccl"), which is what a one-GPU box can run of the real
     exchange: ProcessGroupNCCL stream semantics, bucketed all-reduces spliced into the backward launch list and issued
     with the side stream current (Plan.after_both_streams), Work.wait() on the main stream, 1/world in the SGD kernel."""
@@ -147,9 +192,9 @@ def _one_rank_rccl_main(port, out):
     w_dist, l_dist = steps()
     covered = sorted(r for rs in launched[:dp.n_buckets] for r in rs)
     w0 = w_init.cpu().numpy()
-    out.put(dict(step=float(np.abs(w_plain - w0).max()), spread=float(np.abs(w_plain - w_plain2).max()),
+    out.put(("ok", dict(step=float(np.abs(w_plain - w0).max()), spread=float(np.abs(w_plain - w_plain2).max()),
                  err=float(np.abs(w_dist - w_plain).max()), l_plain=l_plain, l_dist=l_dist,
-                 n_buckets=dp.n_buckets, n_launch=len(launched), covered=covered, n_train=int(st["n_train"])))
+                 n_buckets=dp.n_buckets, n_launch=len(launched), covered=covered, n_train=int(st["n_train"]))))
     torch.distributed.destroy_process_group()
 
 
@@ -162,7 +207,7 @@ def test_one_rank_rccl_exchange_in_the_step(cuda, monkeypatch):
     out = ctx.Queue()
     p = ctx.Process(target=_one_rank_rccl_main, args=(_free_port(), out))
     p.start()
-    res = out.get(timeout=900)
+    res = _collect([p], out, 1)[0][1]
     p.join(timeout=120)
     assert p.exitcode == 0
     assert res["n_buckets"] >= 2 and res["n_launch"] == STEPS * res["n_buckets"]
