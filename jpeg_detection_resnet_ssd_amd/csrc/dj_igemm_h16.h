@@ -160,9 +160,6 @@ __device__ __forceinline__ void dj_split_store3(short* dst, f32x4 v, int lo_off)
 //     this for the fp32 kernels (NP 1 of dj_igemm_fast.h); here the counters say the kernels are bound by instruction ISSUE
 //     (rocprofv3, 1x1 256->1024 @38x38 forward: instructions issuing in 83 % of a SIMD's cycles, matrix pipe busy 18 %, 37 %
 //     of a wave's life waiting for data), and two thirds of the convolutions of a bottleneck block are 1x1.
-#ifndef DJ_H16_ILV
-#define DJ_H16_ILV 1
-#endif
 template <int BM, int BN, int AM, int BMD, int PRO, int PREC, int BK = 32, int PF = 1, int EPI = 0, int AT = 0, int BT = 0, int NP = 0>
 __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p) {
   static_assert(NP == 0 || PRO != 3, "NP: not with the residual-add prologue (which keeps row indices of its own)");
@@ -560,16 +557,6 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dj_bf16x8, f.a[i]), __builtin_bit_cast(dj_bf16x8, f.b[j]), c, 0, 0, 0);
     }
   };
-  auto compute = [&](auto first_tag, const short* sA, const short* sB, int s) {
-    constexpr bool FIRST = decltype(first_tag)::value;   // this MFMA starts its accumulator
-    Frags f;
-    load_frags(f, sA, sB, s);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) mfma_unit(FIRST, f, i, j);
-  };
-
   // two LDS stages: tile kt+1 is stored while tile kt is multiplied
   using First = std::integral_constant<bool, true>;
   using Later = std::integral_constant<bool, false>;
@@ -579,7 +566,6 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
     short* nxt = smem + ((kt + 1) & 1) * STAGE;
     issue_loads(load_into, k_load, live);
     if (PF == 2) __builtin_amdgcn_sched_barrier(0);   // the loads stay up here, a whole step ahead of their LDS stores
-#if DJ_H16_ILV
     {
       // Interleaved K-step.  The matrix pipe takes 32 cycles per MFMA while the wave is free to issue 4-cycle vector
       // instructions, but the compiler's schedule keeps the MFMAs of a slice together and the next tile's prologue /
@@ -608,16 +594,7 @@ __global__ __launch_bounds__(256) void dj_igemm_h16_kernel(const DjIgemmParams p
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      __syncthreads();
-      return;
     }
-#endif
-    if (FIRST) compute(First{}, cur, cur + Cfg::A_H, 0);
-#pragma unroll
-    for (int st = FIRST ? 1 : 0; st < BK / 32; ++st) compute(Later{}, cur, cur + Cfg::A_H, st);
-    store_tiles(store_from, nxt, nxt + Cfg::A_H);
-#pragma unroll
-    for (int st = BK / 32; st < BK / 16; ++st) compute(Later{}, cur, cur + Cfg::A_H, st);
     __syncthreads();
   };
   issue_loads(r0, kbeg, nk > 0);
