@@ -46,6 +46,7 @@ def test_conv_directions_in_split_bf16_arithmetic(geom, mode, floatx):
     xd, wd, dyd = x.cuda(), wt.cuda(), dy.cuda()
     y, dx, dw = torch.empty_like(dyd), torch.empty_like(xd), torch.zeros_like(wd)
     y32, dx32, dw32 = torch.empty_like(dyd), torch.empty_like(xd), torch.zeros_like(wd)
+    floatx.set_floatx("float32_mfma")           # fp32 MFMA instructions only (the default mode may name a split kernel)
     Kn.conv2d_fwd(desc, xd, wd, bias.cuda(), y32)
     Kn.conv2d_dgrad(desc, dyd, wd, dx32)
     Kn.conv2d_wgrad(desc, xd, dyd, dw32)
@@ -160,7 +161,7 @@ def test_training_step_split_modes_meet_the_fp32_bar(archi, floatx):
                                    lr=0.001, momentum=0.9)
     den = sum(float(((ref["new_weights"][k] - wt[k]) ** 2).sum()) for k in w0 if k in ref["new_weights"])
     got = {}
-    for mode in ("float32x3", "float32x6", "float32"):
+    for mode in ("float32x3", "float32x6", "float32_mfma"):
         if mode != "float32x3":
             floatx.clear_session()              # (the same auto-generated layer names as the first build)
         m = model if mode == "float32x3" else workloads.build_ssd(archi)[0]
@@ -169,7 +170,7 @@ def test_training_step_split_modes_meet_the_fp32_bar(archi, floatx):
         loss = m.train_on_batch(x, y_true)
         torch.cuda.synchronize()
         plan = m._plan(2, True, True)
-        assert plan.compute_mode == {"float32x3": 3, "float32x6": 4, "float32": 0}[mode] and not plan.store16
+        assert plan.compute_mode == {"float32x3": 3, "float32x6": 4, "float32_mfma": 5}[mode] and not plan.store16
         y_pred = plan.outputs[0].buf.cpu().double()
         floatx.set_floatx("float32")
         e_pred = float((y_pred - ref["y_pred"]).abs().max()) / float(ref["y_pred"].abs().max())
@@ -183,4 +184,4 @@ def test_training_step_split_modes_meet_the_fp32_bar(archi, floatx):
         assert e_pred <= 1e-3 and e_loss <= 1e-3 and e_upd <= 5e-3, got
     # float32x6 is an fp32 arithmetic: as close to the oracle as the fp32 MFMA kernels' step, within 3x (both are a few ulps
     # of fp32 per GEMM, amplified alike by the batch-of-2 BatchNormalization)
-    assert all(a <= 3.0 * b + 1e-6 for a, b in zip(got["float32x6"], got["float32"])), got
+    assert all(a <= 3.0 * b + 1e-6 for a, b in zip(got["float32x6"], got["float32_mfma"])), got
