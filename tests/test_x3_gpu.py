@@ -66,6 +66,36 @@ def test_conv_directions_in_split_bf16_arithmetic(geom, mode, floatx):
 
 
 @pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("sx,sw,sd", [(1e15, 1e-15, 1e-12), (1e-18, 1e3, 1e10), (3e-30, 1.0, 1e20), (1e25, 1e-10, 1e-20)])
+def test_split_modes_keep_the_fp32_exponent_range(mode, sx, sw, sd, floatx):
+    """bf16 pieces have the exponent range of fp32: operands far from 1 (activations of 1e15 against weights of 1e-15,
+    activations of 3e-30 against gradients of 1e20, ...; every result inside the fp32 range) keep the mode's accuracy -- what an fp16-piece split could not do.  (Documented limits:
+    an operand above the largest bf16, 3.39e38, rounds to infinity where fp32 would still be finite; below ~1e-33 the low
+    pieces are denormal and the relative accuracy of a product falls back towards bf16x2's.)"""
+    from jpeg_detection_resnet_ssd_amd import kernels as Kn
+    from oracle import keras_ops as ko
+    b, h, w, ci, co, k = 4, 19, 19, 256, 128, 3
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(b, h, w, ci, generator=g) * sx
+    wt = torch.randn(k, k, ci, co, generator=g) * (2.0 / (k * k * ci)) ** 0.5 * sw
+    xr, wr = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    yr = ko.conv2d(xr, wr, None, (1, 1), "same")
+    dy = torch.randn(*yr.shape, generator=g) * sd
+    yr.backward(dy.double())
+    desc = Kn.make_conv_desc(b, h, w, ci, co, (k, k), (1, 1), "same", (1, 1))
+    xd, wd, dyd = x.cuda(), wt.cuda(), dy.cuda()
+    y, dx, dw = torch.empty_like(dyd), torch.empty_like(xd), torch.zeros_like(wd)
+    floatx.set_floatx(mode)
+    Kn.conv2d_fwd(desc, xd, wd, None, y)
+    Kn.conv2d_dgrad(desc, dyd, wd, dx)
+    Kn.conv2d_wgrad(desc, xd, dyd, dw)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all() and torch.isfinite(dx).all() and torch.isfinite(dw).all()
+    e = (rel_l2(y.cpu(), yr.detach()), rel_l2(dx.cpu(), xr.grad), rel_l2(dw.cpu(), wr.grad))
+    assert max(e) <= TOL[mode], (e, sx, sw, sd)
+
+
+@pytest.mark.parametrize("mode", MODES)
 def test_split_modes_refuse_16_bit_tensors(mode, floatx):
     """Modes 3 / 4 are arithmetics of fp32 tensors: 16-bit storage belongs to mode 1 and is refused here."""
     from jpeg_detection_resnet_ssd_amd import kernels as Kn
