@@ -329,7 +329,11 @@ def main(json_out=None):
 
     from jpeg_detection_resnet_ssd_amd import dist as djdist
     from jpeg_detection_resnet_ssd_amd import workloads
-    rank, world, local = djdist.init_from_env()      # ranks are initialised before any GPU call
+    # (DJ_BENCH_BACKEND=gloo DJ_BENCH_ONE_CARD=1: rehearsal of the N > 1 command on a one-GPU box -- every rank on card 0,
+    # gradients exchanged over gloo; the driver's run uses neither: RCCL, one card per rank)
+    rank, world, local = djdist.init_from_env(os.environ.get("DJ_BENCH_BACKEND"))      # before any GPU call
+    if os.environ.get("DJ_BENCH_ONE_CARD") == "1":
+        local = 0
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
