@@ -144,12 +144,20 @@ def cpu_baseline(archi, batch, budget_s=25.0):
                       "at batch %d; median step %.2f s" % (len(use), archi, batch, med)}
 
 
-DTYPE_NAME = {"float32": "f32 (fp32 tensors, fp32 accumulation; per layer the fp32 MFMA kernel or the split-bf16 kernel -- 6 bf16 MFMAs "
-                         "on hi/mid/lo operand pieces, dropped terms 2^-24 -- whichever the tuning table measured faster; both are "
-                         "1.4e-7..4.6e-7 rel-L2 from the fp64 oracle per GEMM, tests/test_x3_gpu.py)",
-              "float32_mfma": "f32 (fp32 MFMA instructions only)", "float16": "f16/bf16-mfma+f32-acc", "bfloat16": "bf16-mfma+f32-acc",
-              "float32x3": "f32 tensors, f32 products as 3 bf16 MFMAs on hi/lo split operands (~4e-6 rel per GEMM), f32 acc",
-              "float32x6": "f32 tensors, f32 products as 6 bf16 MFMAs on hi/mid/lo split operands (fp32-grade), f32 acc"}
+# `dtype`: the arithmetic type of the results (a short token); `arithmetic`: how the convolutions get there
+DTYPE_NAME = {"float32": "f32", "float32_mfma": "f32", "float32x6": "f32", "float32x3": "f32-bf16x3",
+              "float16": "f16/bf16-mfma+f32-acc", "bfloat16": "bf16-mfma+f32-acc"}
+ARITHMETIC = {
+    "float32": "fp32 tensors, fp32 accumulation, fp32 results: per layer the fp32 MFMA kernel or the split-bf16 kernel (operands cut "
+               "into three bf16 pieces = all 24 significant bits, six bf16 MFMAs per product, dropped terms 2^-24), whichever the "
+               "tuning table measured faster; both 1.4e-7..4.6e-7 rel-L2 from the fp64 oracle per GEMM (tests/test_x3_gpu.py)",
+    "float32_mfma": "fp32 tensors, fp32 MFMA instructions only (v_mfma_f32_32x32x2_f32)",
+    "float32x6": "fp32 tensors, every product as 6 bf16 MFMAs on hi/mid/lo operand pieces (fp32-grade), fp32 accumulation",
+    "float32x3": "fp32 tensors, every product as 3 bf16 MFMAs on hi/lo operand pieces (~4e-6 rel-L2 per GEMM), fp32 accumulation",
+    "float16": "fp16 MFMA forward / bf16 MFMA gradients, fp32 accumulation; fp16 activations, bf16 gradients, 16-bit weight shadows "
+               "in HBM; fp32 master weights, statistics and optimizer state",
+    "bfloat16": "bf16 MFMA in every GEMM, fp32 accumulation, fp32 tensors",
+}
 
 
 def build_classifier(archi, batch, seed=1234):
@@ -362,7 +370,7 @@ def main(json_out=None):
         "metric": "images/sec (train) ResNet50-DCT-SSD300",
         "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": DTYPE_NAME[args.floatx],
+        "vs_baseline": None, "dtype": DTYPE_NAME[args.floatx], "arithmetic": ARITHMETIC[args.floatx],
         "data": "synthetic",
         "config": {"workload": "SSD300 ResNet50-DCT '%s' archi, %d images/GPU, 300x300 JPEG-DCT inputs "
                                "(Y 38x38x64 + chroma 19x19), fwd+loss+bwd+SGD(+RCCL all-reduce); batch and encoded targets "
@@ -394,7 +402,8 @@ def main(json_out=None):
             sec.append({"config": {"workload": what, "archi": archi, "floatx": floatx, "train_gflop_per_image": gf,
                                    "last_loss": ls},
                         "value": v, "unit": "images/sec", "ms_per_step": 1e3 * el / steps, "steps": steps,
-                        "dtype": DTYPE_NAME[floatx], "roofline": roofline_of(archi, floatx, b2, v, 1, m2, p2)})
+                        "dtype": DTYPE_NAME[floatx], "arithmetic": ARITHMETIC[floatx],
+                        "roofline": roofline_of(archi, floatx, b2, v, 1, m2, p2)})
             print("secondary %s %s: %.1f img/s (%.2f ms/step)" % (archi, floatx, v, 1e3 * el / steps), file=sys.stderr,
                   flush=True)
             del m2, p2
