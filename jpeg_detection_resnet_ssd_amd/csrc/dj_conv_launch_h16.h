@@ -61,11 +61,12 @@ static int launch_h16(const DjIgemmParams& p, int splits, hipStream_t s, int fas
 template <int BM, int BN, int AM, int BMD, int PREC, int PF, int AT, int BT>
 static int launch_h16_depth(const DjIgemmParams& p, int splits, hipStream_t s, int fast, bool deep) {
   static const bool bk32 = getenv("DJ_H16_BK32") != nullptr;   // DJ_H16_BK32=1: 32-deep K-steps only
-  if constexpr (PREC == 4 && BM == 128) {
+  if constexpr (PREC >= 3 && BM == 128) {
     // float32x6, 128-row tiles: three images of a 64-deep stage pair exceed the 160 KB of a CU, and those of a 32-deep one
     // (92-120 KB) leave room for ONE workgroup = one wave per SIMD, with nobody to issue while it waits (counters: matrix
     // pipe 50 % busy, 44 % of the wave's cycles waiting).  The "deep" indices name 16-deep K-steps instead: 56-74 KB, two
-    // workgroups per CU -- all three GEMM roles.
+    // workgroups per CU -- all three GEMM roles.  float32x3 likewise: its 64-deep pair is 110-147 KB, and even the 80 KB of
+    // the 32-deep 128x128 pair runs one workgroup per CU (counters: 0.87 waves per SIMD, matrix pipe 34 % busy); 16-deep: 45 KB.
     if (deep && !bk32 && p.srcC % 16 == 0 && p.kchunk % 16 == 0)
       return launch_h16<BM, BN, AM, BMD, PREC, 16, PF, AT, BT>(p, splits, s, fast);
   } else if constexpr (AM != 2) {

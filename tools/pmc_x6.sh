@@ -3,8 +3,8 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 SHAPE=${SHAPE:-32 38 38 256 256 3}
 MODE=${MODE:-float32x6}
 i=0
-for spec in "fwd_plain 13" "fwd_plain 9" "dgrad 13" "wgrad 13"; do
-  set -- $spec
+for spec in ${SPECS:-fwd_plain:13 fwd_plain:9 dgrad:13 wgrad:13}; do
+  set -- ${spec/:/ }
   i=$((i+1))
   timeout -k 10 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmcx_a$i -- python tools/one_conv32.py $SHAPE $1 $2 $MODE 14 > /dev/null 2>gpurun_out/pmcx_a$i.err || exit 1
   timeout -k 10 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d gpurun_out/pmcx_b$i -- python tools/one_conv32.py $SHAPE $1 $2 $MODE 14 > /dev/null 2>gpurun_out/pmcx_b$i.err || exit 1
